@@ -1,0 +1,154 @@
+/* phylign_match.h -- C ABI of libphylign_match.so, the MI355X-native COBS
+ * classic-index matching stage for Phylign's intermediate/03_match.
+ *
+ * This is the drop-in boundary.  The reference binds to its
+ * engine through a process boundary: `cobs query --load-complete -t T -T N
+ * -i INDEX [--index-sizes BYTES] -f QUERY.fa` (scripts/run_cobs_streaming.sh:24-29,
+ * Snakefile:419-424, Snakefile:476-481) followed by `postprocess_cobs.py -n N`
+ * (Snakefile:425, :467).  The entry points below are what a Python/ctypes (or
+ * cgo / JNI) binding for that path calls instead; phylign_amd/cobs_query.py is
+ * that binding and INTEGRATION.md shows the Snakefile-side change.
+ *
+ * Conventions: every function returns 0 on success or a negative PM_E* code;
+ * pm_last_error() holds the message (thread-local).  No C++ exceptions cross
+ * the boundary.  One process drives one GPU.  There is NO CPU fallback: without
+ * a visible gfx950 device pm_init() fails and every compute entry point
+ * returns PM_ENODEV.
+ */
+#ifndef PHYLIGN_MATCH_H
+#define PHYLIGN_MATCH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK        0
+#define PM_EINVAL   -1   /* bad argument / malformed input */
+#define PM_ENODEV   -2   /* no usable GPU or pm_init() not called */
+#define PM_ENOMEM   -3   /* host or device allocation failed */
+#define PM_EIO      -4   /* read error / short index stream */
+#define PM_EFORMAT  -5   /* not a COBS classic index */
+#define PM_EQUERY   -6   /* query shorter than k, or non-ACGT base */
+#define PM_EHIP     -7   /* HIP runtime error (message has the detail) */
+#define PM_ERANGE   -8   /* size outside what this build supports */
+
+typedef struct pm_index   pm_index_t;    /* one phylogenetic batch index, resident in HBM */
+typedef struct pm_queries pm_queries_t;  /* a parsed query FASTA, resident in HBM */
+typedef struct pm_result  pm_result_t;   /* hits of one pm_search call */
+
+/* Row layout policy in HBM (DESIGN.md "Data layout"). */
+#define PM_LAYOUT_AUTO     0  /* line-aligned stride if it fits, else compact */
+#define PM_LAYOUT_COMPACT  1  /* stride = row_bytes rounded up to 16 */
+#define PM_LAYOUT_ALIGNED  2  /* stride = pow2 (<=128 B) or multiple of 128 B */
+
+typedef struct {
+    uint32_t term_size;        /* k (31 for the 661k indexes) */
+    uint32_t canonicalize;     /* 0/1 */
+    uint64_t signature_size;   /* number of rows S */
+    uint32_t num_hashes;
+    uint32_t n_docs;           /* D */
+    uint64_t row_bytes;        /* ceil(D/8): the algorithmic bytes of one row */
+    uint64_t stride;           /* bytes between rows in HBM (>= row_bytes) */
+    uint64_t device_bytes;     /* HBM held by the matrix */
+    uint32_t header_layout;    /* which header field order validated (0/1) */
+    uint32_t has_matrix;       /* 0 for header-only handles */
+} pm_index_info_t;
+
+/* One hit record, 16 bytes; identical in HBM, on the wire (RCCL) and on host. */
+typedef struct {
+    uint32_t query;   /* index of the FASTA record inside the pm_queries_t */
+    uint32_t doc;     /* document (column) index inside the batch index */
+    uint32_t score;   /* number of matched k-mers */
+    uint32_t slot;    /* position of the index in the pm_search() array (+ slot_base) */
+} pm_hit_t;
+
+typedef struct {
+    uint64_t n_queries, n_terms;     /* FASTA records / k-mers in the query set */
+    uint64_t n_hits;                 /* hits over all slots */
+    uint64_t algorithmic_bytes;      /* sum_slots n_terms * num_hashes * row_bytes */
+    double   ms_total;               /* hipEvent time: hash + row-map + scan kernels */
+    double   ms_hash;                /* canonicalise + XXH64 kernel */
+    double   ms_scan;                /* sum of scan-kernel launch durations */
+    uint32_t n_scan_launches;
+    uint32_t reserved;
+} pm_stats_t;
+
+/* ---- runtime ---------------------------------------------------------- */
+int  pm_init(int device);                 /* bind this process to GPU `device` */
+void pm_shutdown(void);
+const char* pm_last_error(void);
+int  pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus);
+void pm_free(void* p);                    /* frees buffers documented as caller-freed */
+/* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
+uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);
+
+/* ---- index (replaces `cobs query -i`, --load-complete, --index-sizes) --- */
+/* path may be a regular file or a pipe (/dev/fd/N as produced by
+ * run_cobs_streaming.sh:27); size_hint = --index-sizes value or 0. */
+int  pm_index_load_file(const char* path, uint64_t size_hint, int layout, pm_index_t** out);
+int  pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out);
+int  pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out);
+/* header + document names only (no matrix): for the rank that formats text */
+int  pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out);
+/* 661k-shaped synthetic index generated in HBM; header_only!=0
+ * creates just the names table "%05x_SYN%07u". */
+int  pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signature_size,
+                    uint32_t num_hashes, uint32_t term_size, uint64_t seed,
+                    int layout, int header_only, pm_index_t** out);
+/* sets bit (rows[i], docs[i]) for i<n: planted hits for parity runs */
+int  pm_index_plant(pm_index_t* idx, const uint64_t* rows, const uint32_t* docs, size_t n);
+int  pm_index_info(const pm_index_t* idx, pm_index_info_t* info);
+const char* pm_index_doc_name(const pm_index_t* idx, uint32_t doc, size_t* len);
+/* copies the row_bytes logical bytes of one row back to the host (checks) */
+int  pm_index_read_row(const pm_index_t* idx, uint64_t row, void* out);
+void pm_index_free(pm_index_t* idx);
+
+/* ---- queries (replaces `cobs query -f`) ---------------------------------- */
+/* FASTA record rules of the cobs CLI: '>' or ';' starts a record, empty lines
+ * are skipped, sequence lines are concatenated, records with an empty sequence
+ * are dropped.  Fails with PM_EQUERY on a sequence shorter than term_size or
+ * holding a byte outside ACGT. */
+int  pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out);
+int  pm_queries_count(const pm_queries_t* q, uint64_t* n_queries, uint64_t* n_terms);
+/* number of k-mers of record i (length - k + 1) */
+int  pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_terms);
+void pm_queries_free(pm_queries_t* q);
+/* runs the canonicalise+XXH64 kernel and copies hashes[term*num_hashes + j]
+ * (dense, FASTA order) to the host: parity hook for SURVEY row a5 */
+int  pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out);
+
+/* ---- search (replaces the query loop of `cobs query`) -------------------- */
+/* Scores every query against every index of idx[0..n_idx) and keeps documents
+ * with score >= pm_threshold_terms(threshold, terms(query)); threshold 0 keeps
+ * all.  Hits stay in HBM until asked for.  slot_base is added to the slot field
+ * (global batch numbering across ranks). */
+int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+               double threshold, uint32_t slot_base, pm_result_t** out);
+int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
+/* raw (unordered) records in HBM, e.g. as the send buffer of the RCCL gather */
+int  pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n);
+/* D2D copy of the records into caller-owned device memory (a torch tensor) */
+int  pm_result_copy_hits_device(const pm_result_t* r, void* dst_dptr, uint64_t capacity);
+/* records on the host ordered by (slot, query, score desc, doc asc);
+ * library-owned, valid until pm_result_free */
+int  pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n);
+void pm_result_free(pm_result_t* r);
+
+/* ---- text (replaces cobs stdout and, optionally, postprocess_cobs.py) ---- */
+/* Orders `hits` (any order, all slots allowed; only records with slot==slot are
+ * used) the COBS way and renders "*<header>\t<N>\n" + N x "<doc>\t<score>\n"
+ * for every query.  nb_best_hits < 0: plain cobs output.  nb_best_hits >= 0:
+ * additionally applies scripts/postprocess_cobs.py:16-39 (-n nb_best_hits).
+ * *text is malloc'd; release with pm_free(). */
+int  pm_format_hits(const pm_index_t* idx, const pm_queries_t* q,
+                    const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                    int64_t nb_best_hits, char** text, size_t* len);
+/* one-shot: what `cobs query -i INDEX -f FASTA -t T` prints */
+int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
+                   double threshold, int64_t nb_best_hits, char** text, size_t* len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,294 @@
+"""ctypes binding of libphylign_match.so (include/phylign_match.h).
+
+This is the reference-side stub a Phylign maintainer would add to call the
+MI355X stage instead of spawning `cobs query`
+(scripts/run_cobs_streaming.sh:24-29).  Loading fails loudly when the HIP
+extension has not been built; compute calls fail loudly without a gfx950 GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphylign_match.so")
+
+PM_LAYOUT_AUTO, PM_LAYOUT_COMPACT, PM_LAYOUT_ALIGNED = 0, 1, 2
+ERR_NAMES = {-1: "PM_EINVAL", -2: "PM_ENODEV", -3: "PM_ENOMEM", -4: "PM_EIO",
+             -5: "PM_EFORMAT", -6: "PM_EQUERY", -7: "PM_EHIP", -8: "PM_ERANGE"}
+
+
+class PMError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
+                ("signature_size", C.c_uint64), ("num_hashes", C.c_uint32),
+                ("n_docs", C.c_uint32), ("row_bytes", C.c_uint64), ("stride", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("header_layout", C.c_uint32), ("has_matrix", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n_terms", C.c_uint64), ("n_hits", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("ms_total", C.c_double), ("ms_hash", C.c_double),
+                ("ms_scan", C.c_double), ("n_scan_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("query", "<u4"), ("doc", "<u4"), ("score", "<u4"), ("slot", "<u4")])
+
+# every symbol include/phylign_match.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("pm_init", C.c_int, [C.c_int]),
+    ("pm_shutdown", None, []),
+    ("pm_last_error", C.c_char_p, []),
+    ("pm_device_info", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    ("pm_free", None, [_P]),
+    ("pm_threshold_terms", C.c_uint32, [C.c_double, C.c_uint64]),
+    ("pm_index_load_file", C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(_P)]),
+    ("pm_index_load_fd", C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(_P)]),
+    ("pm_index_load_mem", C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
+    ("pm_index_load_header_mem", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("pm_index_synth", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("pm_index_plant", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("pm_index_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
+    ("pm_index_doc_name", _P, [_P, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("pm_index_read_row", C.c_int, [_P, C.c_uint64, _P]),
+    ("pm_index_free", None, [_P]),
+    ("pm_queries_parse", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    ("pm_queries_count", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("pm_queries_terms", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("pm_queries_free", None, [_P]),
+    ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
+    ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.POINTER(_P)]),
+    ("pm_result_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("pm_result_hits_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64]),
+    ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("pm_result_free", None, [_P]),
+    ("pm_format_hits", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pm_query_text", C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_double, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the gfx950 HIP extension first "
+                "(python -m phylign_amd.build or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise PMError(rc, load().pm_last_error().decode(errors="replace"))
+
+
+_inited_device = None
+
+
+def init(device=0):
+    global _inited_device
+    _chk(load().pm_init(device))
+    _inited_device = device
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    tot, fr, cus = C.c_uint64(), C.c_uint64(), C.c_int()
+    _chk(load().pm_device_info(name, 256, C.byref(tot), C.byref(fr), C.byref(cus)))
+    return {"name": name.value.decode(), "hbm_total": tot.value, "hbm_free": fr.value, "cus": cus.value}
+
+
+def threshold_terms(threshold, num_terms):
+    return load().pm_threshold_terms(threshold, num_terms)
+
+
+class Index:
+    """One phylogenetic batch index resident in HBM (or header-only)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load_file(cls, path, size_hint=0, layout=PM_LAYOUT_AUTO):
+        h = _P()
+        _chk(load().pm_index_load_file(os.fsencode(path), size_hint, layout, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_fd(cls, fd, size_hint=0, layout=PM_LAYOUT_AUTO):
+        h = _P()
+        _chk(load().pm_index_load_fd(fd, size_hint, layout, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_mem(cls, buf, layout=PM_LAYOUT_AUTO):
+        a = np.frombuffer(buf, dtype=np.uint8)
+        h = _P()
+        _chk(load().pm_index_load_mem(a.ctypes.data, a.size, layout, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_header_mem(cls, buf):
+        a = np.frombuffer(buf, dtype=np.uint8)
+        h = _P()
+        _chk(load().pm_index_load_header_mem(a.ctypes.data, a.size, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synth(cls, batch_id, n_docs, signature_size, num_hashes=1, term_size=31, seed=661,
+              layout=PM_LAYOUT_AUTO, header_only=False):
+        h = _P()
+        _chk(load().pm_index_synth(batch_id, n_docs, signature_size, num_hashes, term_size, seed,
+                                   layout, int(header_only), C.byref(h)))
+        return cls(h)
+
+    def plant(self, rows, docs):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        docs = np.ascontiguousarray(docs, dtype=np.uint32)
+        assert rows.size == docs.size
+        _chk(load().pm_index_plant(self._h, rows.ctypes.data, docs.ctypes.data, rows.size))
+
+    @property
+    def info(self):
+        i = IndexInfo()
+        _chk(load().pm_index_info(self._h, C.byref(i)))
+        return i
+
+    def doc_name(self, d):
+        n = C.c_size_t()
+        p = load().pm_index_doc_name(self._h, d, C.byref(n))
+        if not p:
+            raise IndexError(d)
+        return C.string_at(p, n.value).decode()
+
+    def read_row(self, row):
+        out = np.zeros(self.info.row_bytes, dtype=np.uint8)
+        _chk(load().pm_index_read_row(self._h, row, out.ctypes.data))
+        return out
+
+    def free(self):
+        if self._h:
+            load().pm_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Queries:
+    """A query FASTA parsed with the cobs CLI's record rules, resident in HBM."""
+
+    def __init__(self, fasta: bytes, term_size=31):
+        h = _P()
+        _chk(load().pm_queries_parse(fasta, len(fasta), term_size, C.byref(h)))
+        self._h = h
+
+    def count(self):
+        nq, nt = C.c_uint64(), C.c_uint64()
+        _chk(load().pm_queries_count(self._h, C.byref(nq), C.byref(nt)))
+        return nq.value, nt.value
+
+    def terms(self, i):
+        n = C.c_uint64()
+        _chk(load().pm_queries_terms(self._h, i, C.byref(n)))
+        return n.value
+
+    def hash_terms(self, canonicalize=1, num_hashes=1):
+        _, nt = self.count()
+        out = np.zeros(nt * num_hashes, dtype=np.uint64)
+        _chk(load().pm_hash_terms(self._h, canonicalize, num_hashes, out.ctypes.data))
+        return out
+
+    def free(self):
+        if self._h:
+            load().pm_queries_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Result:
+    def __init__(self, handle):
+        self._h = handle
+
+    @property
+    def stats(self):
+        s = Stats()
+        _chk(load().pm_result_stats(self._h, C.byref(s)))
+        return s
+
+    def hits_device(self):
+        p, n = _P(), C.c_uint64()
+        _chk(load().pm_result_hits_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def copy_hits_device(self, dst_ptr, capacity):
+        _chk(load().pm_result_copy_hits_device(self._h, dst_ptr, capacity))
+
+    def hits(self):
+        """numpy structured array (HIT_DTYPE) ordered (slot, query, score desc, doc asc)."""
+        p, n = _P(), C.c_uint64()
+        _chk(load().pm_result_hits_host(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        buf = C.string_at(p.value, n.value * HIT_DTYPE.itemsize)
+        return np.frombuffer(buf, dtype=HIT_DTYPE).copy()
+
+    def free(self):
+        if self._h:
+            load().pm_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def search(indexes, queries: Queries, threshold: float, slot_base=0) -> Result:
+    arr = (_P * len(indexes))(*[ix._h for ix in indexes])
+    h = _P()
+    _chk(load().pm_search(arr, len(indexes), queries._h, threshold, slot_base, C.byref(h)))
+    return Result(h)
+
+
+def format_hits(index: Index, queries: Queries, hits, slot=0, nb_best_hits=-1) -> bytes:
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    t, n = _P(), C.c_size_t()
+    _chk(load().pm_format_hits(index._h, queries._h, hits.ctypes.data, hits.size, slot, nb_best_hits,
+                               C.byref(t), C.byref(n)))
+    out = C.string_at(t.value, n.value)
+    load().pm_free(t)
+    return out
+
+
+def query_text(index: Index, fasta: bytes, threshold: float, nb_best_hits=-1) -> bytes:
+    t, n = _P(), C.c_size_t()
+    _chk(load().pm_query_text(index._h, fasta, len(fasta), threshold, nb_best_hits, C.byref(t), C.byref(n)))
+    out = C.string_at(t.value, n.value)
+    load().pm_free(t)
+    return out

@@ -1,0 +1,864 @@
+// pm_host.cpp -- host side of libphylign_match.so: C ABI (include/phylign_match.h),
+// COBS classic-index reader, FASTA reader with the cobs CLI's
+// record rules (a5 input), search orchestration on a HIP stream (a5-a7), COBS
+// result ordering and text (a7) and the fused post-filter (a8).
+//
+// The reference reaches this functionality through `cobs query ...`
+// (scripts/run_cobs_streaming.sh:24-29; Snakefile:419-424, :476-481) and
+// `postprocess_cobs.py -n N` (scripts/postprocess_cobs.py:21-39).
+// No CPU fallback exists in this file: scoring happens only in pm_kernels.hip.
+#include "../../include/phylign_match.h"
+#include "pm_internal.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+using namespace pm;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);             \
+    } while (0)
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+};
+static Ctx g_ctx;
+#define NEED_DEV()                                                                         \
+    do {                                                                                   \
+        if (!g_ctx.ready) return fail(PM_ENODEV, "pm_init() has not succeeded: no GPU bound (there is no CPU fallback)"); \
+    } while (0)
+
+// ------------------------------------------------------------------ objects
+struct pm_index {
+    pm_index_info_t info{};
+    std::string names_blob;            // all names, '\0' separated
+    std::vector<uint64_t> name_off;    // n_docs + 1
+    uint8_t* d_matrix = nullptr;
+    int g = 1;                         // lanes per row
+    uint32_t slabs = 1;
+};
+
+struct pm_queries {
+    uint32_t k = 0;
+    std::vector<std::string> headers;       // header line without its first byte
+    std::vector<uint32_t> n_terms;
+    uint64_t total_terms = 0;
+    uint64_t n_slots = 0;                   // padded to 8 per query
+    std::vector<QDesc> qd;
+    // plane classes: queries ordered by class, ranges per class
+    std::vector<uint32_t> qmap;
+    uint32_t class_begin[5] = {0, 0, 0, 0, 0};
+    // device
+    uint8_t* d_seq = nullptr;
+    QDesc* d_qd = nullptr;
+    uint32_t* d_blkq = nullptr;
+    uint32_t* d_qmap = nullptr;
+    uint64_t* d_hashes = nullptr;
+    int hash_canon = -1; uint32_t hash_nh = 0;
+};
+
+struct pm_result {
+    uint4* d_hits = nullptr;
+    uint64_t cap = 0;
+    uint64_t n_hits = 0;
+    pm_stats_t st{};
+    std::vector<pm_hit_t> host;
+    bool host_ready = false;
+};
+
+static const int kPlaneClass[4] = {7, 10, 16, 24};
+
+// ------------------------------------------------------------------ runtime
+extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pm_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PM_ENODEV, "no HIP device visible (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(PM_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PM_ENODEV, "device %d is %s; this build targets gfx950 only", device, prop.gcnArchName);
+    if (g_ctx.ready && g_ctx.device == device) return PM_OK;
+    if (g_ctx.ready) pm_shutdown();
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
+    g_ctx.device = device;
+    g_ctx.ready = true;
+    return PM_OK;
+}
+
+extern "C" void pm_shutdown(void) {
+    if (!g_ctx.ready) return;
+    hipStreamDestroy(g_ctx.stream);
+    hipStreamDestroy(g_ctx.copy_stream);
+    g_ctx = Ctx();
+}
+
+extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus) {
+    NEED_DEV();
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g_ctx.device));
+    if (name && cap) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    if (hbm_total) *hbm_total = tot;
+    if (hbm_free) *hbm_free = fr;
+    if (n_cus) *n_cus = prop.multiProcessorCount;
+    return PM_OK;
+}
+
+extern "C" void pm_free(void* p) { free(p); }
+
+// The ONE place that turns `-t` into a minimum score (cobs counts_to_result):
+// ceil(threshold * num_terms) in IEEE double.  config.yaml:20 -> Snakefile:410.
+extern "C" uint32_t pm_threshold_terms(double threshold, uint64_t num_terms) {
+    double t = std::ceil(threshold * (double)num_terms);
+    if (!(t > 0)) return 0;
+    if (t > 4294967295.0) return 4294967295u;
+    return (uint32_t)t;
+}
+
+// ---------------------------------------------------- classic index header
+// "COBS:" "CLASSIC_INDEX" u32 version, then the fields, the newline-terminated
+// document names and a closing "CLASSIC_INDEX"; the matrix follows.  The field
+// order cannot be checked against a real file here, so both plausible orders
+// are tried and the one whose closing magic (and version/k sanity) validates
+// is taken.  Returns 0 ok, 1 need more bytes, <0 error.
+struct ParsedHeader {
+    uint32_t version = 0, term_size = 0, n_docs = 0;
+    uint8_t canon = 0;
+    uint64_t sig = 0, nh = 0;
+    size_t names_off = 0, data_off = 0;
+    int layout = 0;
+};
+static int try_header(const uint8_t* b, size_t len, int layout, ParsedHeader& h) {
+    size_t o = 18;
+    const size_t fixed = 4 + 4 + 1 + 4 + 8 + 8;
+    if (len < o + fixed) return 1;
+    auto rd32 = [&](size_t at) { uint32_t v; memcpy(&v, b + at, 4); return v; };
+    auto rd64 = [&](size_t at) { uint64_t v; memcpy(&v, b + at, 8); return v; };
+    h.version = rd32(o); o += 4;
+    h.term_size = rd32(o); o += 4;
+    h.canon = b[o]; o += 1;
+    if (layout == 0) { h.n_docs = rd32(o); o += 4; h.sig = rd64(o); o += 8; h.nh = rd64(o); o += 8; }
+    else             { h.sig = rd64(o); o += 8; h.nh = rd64(o); o += 8; h.n_docs = rd32(o); o += 4; }
+    if (h.version != 1 || h.term_size == 0 || h.term_size > 4096 || h.canon > 1) return -1;
+    if (h.sig == 0 || h.nh == 0 || h.nh > 64) return -1;
+    h.names_off = o;
+    for (uint32_t d = 0; d < h.n_docs; ++d) {
+        if (o >= len) return 1;
+        const void* nl = memchr(b + o, '\n', len - o);
+        if (!nl) return (len - o > (1u << 20)) ? -1 : 1;   // a 1 MiB "name" is not a name
+        o = (size_t)((const uint8_t*)nl - b) + 1;
+    }
+    if (o + 13 > len) return 1;
+    if (memcmp(b + o, "CLASSIC_INDEX", 13) != 0) return -1;
+    h.data_off = o + 13;
+    h.layout = layout;
+    return 0;
+}
+static int parse_header(const uint8_t* b, size_t len, ParsedHeader& h) {
+    if (len < 18) return 1;
+    if (memcmp(b, "COBS:", 5) != 0 || memcmp(b + 5, "CLASSIC_INDEX", 13) != 0) return -1;
+    int need_more = 0;
+    for (int layout = 0; layout < 2; ++layout) {
+        ParsedHeader t;
+        int rc = try_header(b, len, layout, t);
+        if (rc == 0) { h = t; return 0; }
+        if (rc == 1) need_more = 1;
+    }
+    return need_more ? 1 : -1;
+}
+
+static uint64_t pow2ceil(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+static uint64_t stride_compact(uint64_t rb) { return std::max<uint64_t>(16, (rb + 15) / 16 * 16); }
+static uint64_t stride_aligned(uint64_t rb) {
+    if (rb <= 16) return 16;
+    if (rb <= 128) return pow2ceil(rb);
+    return (rb + 127) / 128 * 128;
+}
+
+static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, bool want_matrix) {
+    pm_index_info_t& in = ix->info;
+    in.term_size = h.term_size; in.canonicalize = h.canon; in.signature_size = h.sig;
+    in.num_hashes = (uint32_t)h.nh; in.n_docs = h.n_docs;
+    in.row_bytes = ((uint64_t)h.n_docs + 7) / 8;
+    in.header_layout = (uint32_t)h.layout;
+    in.has_matrix = 0; in.stride = 0; in.device_bytes = 0;
+    if (!want_matrix) return PM_OK;
+    if (h.sig > 0xFFFFFFFFull) return fail(PM_ERANGE, "signature_size %llu >= 2^32 rows is not supported by this build", (unsigned long long)h.sig);
+    if (in.row_bytes == 0) return fail(PM_EFORMAT, "index holds no documents");
+    uint64_t sc = stride_compact(in.row_bytes), sa = stride_aligned(in.row_bytes);
+    uint64_t stride = sc;
+    if (layout == PM_LAYOUT_ALIGNED) stride = sa;
+    else if (layout == PM_LAYOUT_AUTO) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) return fail(PM_EHIP, "hipMemGetInfo failed");
+        // keep 6% of HBM or 2 GiB free for query state and hit buffers
+        uint64_t reserve = std::max<uint64_t>((uint64_t)tot / 16, 2ull << 30);
+        stride = (h.sig * sa + reserve <= (uint64_t)fr) ? sa : sc;
+    } else if (layout != PM_LAYOUT_COMPACT) return fail(PM_EINVAL, "unknown layout %d", layout);
+    in.stride = stride;
+    in.device_bytes = h.sig * stride;
+    uint64_t lanes = (std::min<uint64_t>(stride, 1024) + 15) / 16;
+    ix->g = (int)pow2ceil(lanes);
+    ix->slabs = (uint32_t)((stride + 1023) / 1024);
+    hipError_t e = hipMalloc((void**)&ix->d_matrix, in.device_bytes);
+    if (e != hipSuccess) return fail(PM_ENOMEM, "hipMalloc(%llu bytes) for the signature matrix failed: %s",
+                                     (unsigned long long)in.device_bytes, hipGetErrorString(e));
+    in.has_matrix = 1;
+    return PM_OK;
+}
+
+static void take_names(pm_index* ix, const uint8_t* b, const ParsedHeader& h) {
+    ix->name_off.resize((size_t)h.n_docs + 1);
+    size_t o = h.names_off;
+    for (uint32_t d = 0; d < h.n_docs; ++d) {
+        const uint8_t* nl = (const uint8_t*)memchr(b + o, '\n', h.data_off - o);
+        size_t l = (size_t)(nl - (b + o));
+        ix->name_off[d] = ix->names_blob.size();
+        ix->names_blob.append((const char*)b + o, l);
+        ix->names_blob.push_back('\0');
+        o += l + 1;
+    }
+    ix->name_off[h.n_docs] = ix->names_blob.size();
+}
+
+// Byte source with push-back, so the header bytes read ahead can be re-used.
+struct Reader {
+    int fd = -1;
+    const uint8_t* mem = nullptr; size_t mem_len = 0, mem_pos = 0;
+    std::vector<uint8_t> pending; size_t pend_pos = 0;
+    // returns bytes read (< n only at EOF), -1 on error
+    ssize_t read_full(uint8_t* dst, size_t n) {
+        size_t got = 0;
+        if (pend_pos < pending.size()) {
+            size_t t = std::min(n, pending.size() - pend_pos);
+            memcpy(dst, pending.data() + pend_pos, t); pend_pos += t; got += t;
+        }
+        if (mem) {
+            size_t t = std::min(n - got, mem_len - mem_pos);
+            memcpy(dst + got, mem + mem_pos, t); mem_pos += t; got += t;
+            return (ssize_t)got;
+        }
+        while (got < n) {
+            ssize_t r = ::read(fd, dst + got, n - got);
+            if (r < 0) { if (errno == EINTR) continue; return -1; }
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        return (ssize_t)got;
+    }
+};
+
+static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool header_only, pm_index_t** out) {
+    // 1. header: read ahead until it parses
+    std::vector<uint8_t> head;
+    size_t want = 1 << 16;
+    ParsedHeader h;
+    for (;;) {
+        size_t old = head.size();
+        head.resize(want);
+        ssize_t r = rd.read_full(head.data() + old, want - old);
+        if (r < 0) return fail(PM_EIO, "read error on index stream: %s", strerror(errno));
+        head.resize(old + (size_t)r);
+        int rc = parse_header(head.data(), head.size(), h);
+        if (rc == 0) break;
+        if (rc < 0) return fail(PM_EFORMAT, "input is not a COBS classic index (magic/version/field check failed)");
+        if ((size_t)r < want - old) return fail(PM_EFORMAT, "index stream ended inside the header");
+        want *= 2;
+        if (want > (1ull << 31)) return fail(PM_EFORMAT, "classic index header larger than 2 GiB");
+    }
+    pm_index* ix = new pm_index();
+    take_names(ix, head.data(), h);
+    int rc = finish_index_shape(ix, h, layout, !header_only);
+    if (rc) { delete ix; return rc; }
+    if (header_only) { *out = ix; return PM_OK; }
+    const uint64_t rb = ix->info.row_bytes, S = h.sig, stride = ix->info.stride;
+    if (size_hint && size_hint != h.data_off + S * rb)
+        fprintf(stderr, "phylign_match: warning: --index-sizes %llu != header-implied %llu bytes\n",
+                (unsigned long long)size_hint, (unsigned long long)(h.data_off + S * rb));
+    rd.pending.assign(head.begin() + (long)h.data_off, head.end());
+    rd.pend_pos = 0;
+
+    // 2. matrix: double-buffered pinned chunks -> staging -> restride kernel
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (32ull << 20) / rb);
+    const size_t chunk_bytes = (size_t)(chunk_rows * rb);
+    uint8_t* hbuf[2] = {nullptr, nullptr};
+    uint8_t* dbuf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            if (hbuf[i]) hipHostFree(hbuf[i]);
+            if (dbuf[i]) hipFree(dbuf[i]);
+            if (ev[i]) hipEventDestroy(ev[i]);
+        }
+    };
+#define LCHK(expr)                                                                        \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            cleanup(); pm_index_free(ix);                                                 \
+            return fail(PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_));                 \
+        }                                                                                 \
+    } while (0)
+    for (int i = 0; i < 2; ++i) {
+        LCHK(hipHostMalloc((void**)&hbuf[i], chunk_bytes, hipHostMallocDefault));
+        LCHK(hipMalloc((void**)&dbuf[i], chunk_bytes));
+        LCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    uint64_t row = 0; int cur = 0; bool used[2] = {false, false};
+    while (row < S) {
+        const uint64_t nrows = std::min<uint64_t>(chunk_rows, S - row);
+        const size_t nbytes = (size_t)(nrows * rb);
+        if (used[cur]) LCHK(hipEventSynchronize(ev[cur]));
+        ssize_t r = rd.read_full(hbuf[cur], nbytes);
+        if (r < 0 || (size_t)r != nbytes) {
+            cleanup(); pm_index_free(ix);
+            return fail(PM_EIO, "index stream ended after %llu of %llu matrix bytes",
+                        (unsigned long long)(row * rb + (r > 0 ? (uint64_t)r : 0)), (unsigned long long)(S * rb));
+        }
+        LCHK(hipMemcpyAsync(dbuf[cur], hbuf[cur], nbytes, hipMemcpyHostToDevice, g_ctx.stream));
+        LCHK(launch_restride(dbuf[cur], rb, ix->d_matrix + row * stride, stride, nrows, g_ctx.stream));
+        LCHK(hipEventRecord(ev[cur], g_ctx.stream));
+        used[cur] = true;
+        row += nrows; cur ^= 1;
+    }
+    LCHK(hipStreamSynchronize(g_ctx.stream));
+#undef LCHK
+    cleanup();
+    *out = ix;
+    return PM_OK;
+}
+
+extern "C" int pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out) {
+    NEED_DEV();
+    if (!out || fd < 0) return fail(PM_EINVAL, "bad argument");
+    Reader rd; rd.fd = fd;
+    return load_from_reader(rd, size_hint, layout, false, out);
+}
+extern "C" int pm_index_load_file(const char* path, uint64_t size_hint, int layout, pm_index_t** out) {
+    NEED_DEV();
+    if (!path || !out) return fail(PM_EINVAL, "bad argument");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(PM_EIO, "cannot open index '%s': %s", path, strerror(errno));
+    int rc = pm_index_load_fd(fd, size_hint, layout, out);
+    close(fd);
+    return rc;
+}
+extern "C" int pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out) {
+    NEED_DEV();
+    if (!buf || !out) return fail(PM_EINVAL, "bad argument");
+    Reader rd; rd.mem = (const uint8_t*)buf; rd.mem_len = len;
+    return load_from_reader(rd, 0, layout, false, out);
+}
+extern "C" int pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out) {
+    if (!buf || !out) return fail(PM_EINVAL, "bad argument");
+    Reader rd; rd.mem = (const uint8_t*)buf; rd.mem_len = len;
+    return load_from_reader(rd, 0, PM_LAYOUT_COMPACT, true, out);
+}
+
+static uint64_t host_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+extern "C" int pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signature_size,
+                              uint32_t num_hashes, uint32_t term_size, uint64_t seed,
+                              int layout, int header_only, pm_index_t** out) {
+    if (!out || n_docs == 0 || signature_size == 0 || num_hashes == 0 || term_size == 0)
+        return fail(PM_EINVAL, "bad synthetic index shape");
+    if (!header_only) NEED_DEV();
+    pm_index* ix = new pm_index();
+    ParsedHeader h;
+    h.version = 1; h.term_size = term_size; h.canon = 1; h.sig = signature_size; h.nh = num_hashes;
+    h.n_docs = n_docs; h.layout = 0;
+    // names "<5 hex>_SYN<batch>D<doc>": a pseudo-random sorting prefix, one underscore
+    const uint64_t kb = host_splitmix64(seed ^ ((uint64_t)batch_id * 0xD1B54A32D192ED03ULL));
+    ix->name_off.resize((size_t)n_docs + 1);
+    char nm[64];
+    for (uint32_t d = 0; d < n_docs; ++d) {
+        int l = snprintf(nm, sizeof nm, "%05x_SYN%03uD%07u",
+                         (unsigned)(host_splitmix64(kb ^ (0xA5A5A5A5ull + d)) & 0xFFFFF), batch_id, d);
+        ix->name_off[d] = ix->names_blob.size();
+        ix->names_blob.append(nm, (size_t)l);
+        ix->names_blob.push_back('\0');
+    }
+    ix->name_off[n_docs] = ix->names_blob.size();
+    int rc = finish_index_shape(ix, h, layout, !header_only);
+    if (rc) { delete ix; return rc; }
+    if (!header_only) {
+        hipError_t e = launch_synth(ix->d_matrix, ix->info.stride, signature_size, n_docs, seed, batch_id, g_ctx.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+        if (e != hipSuccess) { pm_index_free(ix); return fail(PM_EHIP, "synthetic generator: %s", hipGetErrorString(e)); }
+    }
+    *out = ix;
+    return PM_OK;
+}
+
+extern "C" int pm_index_plant(pm_index_t* ix, const uint64_t* rows, const uint32_t* docs, size_t n) {
+    NEED_DEV();
+    if (!ix || !ix->d_matrix) return fail(PM_EINVAL, "index has no matrix");
+    if (n == 0) return PM_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (rows[i] >= ix->info.signature_size || docs[i] >= ix->info.n_docs)
+            return fail(PM_EINVAL, "plant %zu out of range", i);
+    uint64_t* dr = nullptr; uint32_t* dd = nullptr;
+    HIPCHK(hipMalloc((void**)&dr, n * 8));
+    hipError_t e = hipMalloc((void**)&dd, n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr, rows, n * 8, hipMemcpyHostToDevice, g_ctx.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd, docs, n * 4, hipMemcpyHostToDevice, g_ctx.stream);
+    if (e == hipSuccess) e = launch_plant(ix->d_matrix, ix->info.stride, dr, dd, n, g_ctx.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+    hipFree(dr); if (dd) hipFree(dd);
+    if (e != hipSuccess) return fail(PM_EHIP, "plant: %s", hipGetErrorString(e));
+    return PM_OK;
+}
+
+extern "C" int pm_index_info(const pm_index_t* ix, pm_index_info_t* info) {
+    if (!ix || !info) return fail(PM_EINVAL, "bad argument");
+    *info = ix->info;
+    return PM_OK;
+}
+extern "C" const char* pm_index_doc_name(const pm_index_t* ix, uint32_t doc, size_t* len) {
+    if (!ix || doc >= ix->info.n_docs) return nullptr;
+    if (len) *len = (size_t)(ix->name_off[doc + 1] - ix->name_off[doc] - 1);
+    return ix->names_blob.data() + ix->name_off[doc];
+}
+extern "C" int pm_index_read_row(const pm_index_t* ix, uint64_t row, void* out) {
+    NEED_DEV();
+    if (!ix || !ix->d_matrix || !out || row >= ix->info.signature_size) return fail(PM_EINVAL, "bad argument");
+    HIPCHK(hipMemcpy(out, ix->d_matrix + row * ix->info.stride, ix->info.row_bytes, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+extern "C" void pm_index_free(pm_index_t* ix) {
+    if (!ix) return;
+    if (ix->d_matrix) hipFree(ix->d_matrix);
+    delete ix;
+}
+
+// ------------------------------------------------------------------ queries
+// Record rules of `cobs query -f` (upstream src/main.cpp process_query): see
+// include/phylign_match.h.  The input contract (upper-case ACGT, single line)
+// is produced by Snakefile:314-333.
+extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
+    NEED_DEV();
+    if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
+    pm_queries* q = new pm_queries();
+    q->k = term_size;
+    std::string seqs;            // packed sequences
+    std::vector<uint64_t> seq_off;
+    std::string cur_hdr, cur_seq;
+    bool have_any = false;
+    int rc = PM_OK;
+    auto flush = [&]() -> int {
+        if (cur_seq.empty()) return PM_OK;
+        if (cur_seq.size() < term_size)
+            return fail(PM_EQUERY, "query '%s' too short: %zu < %u characters", cur_hdr.c_str(), cur_seq.size(), term_size);
+        for (size_t i = 0; i < cur_seq.size(); ++i) {
+            const char c = cur_seq[i];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T')
+                return fail(PM_EQUERY, "query '%s': byte 0x%02x at position %zu is not one of ACGT "
+                            "(Phylign's fix_query step maps such bases to A)", cur_hdr.c_str(), (unsigned char)c, i);
+        }
+        const uint64_t nt = cur_seq.size() - term_size + 1;
+        if (nt >= (1ull << 24)) return fail(PM_ERANGE, "query '%s' has %llu k-mers; this build supports < 2^24 per query",
+                                            cur_hdr.c_str(), (unsigned long long)nt);
+        q->headers.push_back(cur_hdr);
+        q->n_terms.push_back((uint32_t)nt);
+        seq_off.push_back(seqs.size());
+        seqs += cur_seq;
+        return PM_OK;
+    };
+    size_t p = 0;
+    while (p < len && rc == PM_OK) {
+        const char* nl = (const char*)memchr(fasta + p, '\n', len - p);
+        size_t ll = nl ? (size_t)(nl - (fasta + p)) : len - p;
+        const char* line = fasta + p;
+        p += ll + (nl ? 1 : 0);
+        if (ll == 0) continue;
+        if (line[0] == '>' || line[0] == ';') {
+            rc = flush();
+            cur_hdr.assign(line + 1, ll - 1);
+            cur_seq.clear();
+            have_any = true;
+        } else {
+            cur_seq.append(line, ll);
+        }
+    }
+    (void)have_any;
+    if (rc == PM_OK) rc = flush();
+    if (rc != PM_OK) { delete q; return rc; }
+
+    const size_t nq = q->headers.size();
+    if (nq >= 0xFFFFFFFFull) { delete q; return fail(PM_ERANGE, "too many queries"); }
+    q->qd.resize(nq);
+    uint64_t blk = 0;
+    for (size_t i = 0; i < nq; ++i) {
+        q->qd[i].n_terms = q->n_terms[i];
+        q->qd[i].pad_blk = (uint32_t)blk;
+        q->qd[i].seq_lo = (uint32_t)seq_off[i];
+        q->qd[i].seq_hi = (uint32_t)(seq_off[i] >> 32);
+        blk += (q->n_terms[i] + 7) / 8;
+        q->total_terms += q->n_terms[i];
+        if (blk >= 0xFFFFFFFFull) { delete q; return fail(PM_ERANGE, "query set too large (>= 2^35 padded k-mers)"); }
+    }
+    q->n_slots = blk * 8;
+    std::vector<uint32_t> blkq((size_t)blk);
+    for (size_t i = 0; i < nq; ++i) {
+        uint64_t b0 = q->qd[i].pad_blk, nb = (q->n_terms[i] + 7) / 8;
+        for (uint64_t b = 0; b < nb; ++b) blkq[(size_t)(b0 + b)] = (uint32_t)i;
+    }
+    // plane classes (counter width): stable partition of query ids by class
+    auto cls = [](uint32_t nt) { return nt <= 127 ? 0 : nt <= 1023 ? 1 : nt <= 65535 ? 2 : 3; };
+    q->qmap.reserve(nq);
+    for (int c = 0; c < 4; ++c) {
+        q->class_begin[c] = (uint32_t)q->qmap.size();
+        for (size_t i = 0; i < nq; ++i) if (cls(q->n_terms[i]) == c) q->qmap.push_back((uint32_t)i);
+    }
+    q->class_begin[4] = (uint32_t)q->qmap.size();
+
+    auto bail = [&](hipError_t e, const char* what) {
+        pm_queries_free(q);
+        return fail(e == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    if (nq) {
+        if ((e = hipMalloc((void**)&q->d_seq, std::max<size_t>(seqs.size(), 16))) != hipSuccess) return bail(e, "hipMalloc seq");
+        if ((e = hipMalloc((void**)&q->d_qd, nq * sizeof(QDesc))) != hipSuccess) return bail(e, "hipMalloc qd");
+        if ((e = hipMalloc((void**)&q->d_blkq, std::max<size_t>(blkq.size(), 1) * 4)) != hipSuccess) return bail(e, "hipMalloc blkq");
+        if ((e = hipMalloc((void**)&q->d_qmap, nq * 4)) != hipSuccess) return bail(e, "hipMalloc qmap");
+        if ((e = hipMemcpy(q->d_seq, seqs.data(), seqs.size(), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D seq");
+        if ((e = hipMemcpy(q->d_qd, q->qd.data(), nq * sizeof(QDesc), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D qd");
+        if ((e = hipMemcpy(q->d_blkq, blkq.data(), blkq.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D blkq");
+        if ((e = hipMemcpy(q->d_qmap, q->qmap.data(), nq * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D qmap");
+    }
+    *out = q;
+    return PM_OK;
+}
+
+extern "C" int pm_queries_count(const pm_queries_t* q, uint64_t* n_queries, uint64_t* n_terms) {
+    if (!q) return fail(PM_EINVAL, "bad argument");
+    if (n_queries) *n_queries = q->headers.size();
+    if (n_terms) *n_terms = q->total_terms;
+    return PM_OK;
+}
+extern "C" int pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_terms) {
+    if (!q || i >= q->n_terms.size() || !n_terms) return fail(PM_EINVAL, "bad argument");
+    *n_terms = q->n_terms[(size_t)i];
+    return PM_OK;
+}
+extern "C" void pm_queries_free(pm_queries_t* q) {
+    if (!q) return;
+    if (q->d_seq) hipFree(q->d_seq);
+    if (q->d_qd) hipFree(q->d_qd);
+    if (q->d_blkq) hipFree(q->d_blkq);
+    if (q->d_qmap) hipFree(q->d_qmap);
+    if (q->d_hashes) hipFree(q->d_hashes);
+    delete q;
+}
+
+// hashes for (canonicalize, num_hashes), cached on the query set
+static int ensure_hashes(pm_queries* q, int canon, uint32_t nh) {
+    if (q->d_hashes && q->hash_canon == canon && q->hash_nh == nh) return PM_OK;
+    if (q->d_hashes) { hipFree(q->d_hashes); q->d_hashes = nullptr; }
+    if (q->n_slots == 0) { q->hash_canon = canon; q->hash_nh = nh; return PM_OK; }
+    HIPCHK(hipMalloc((void**)&q->d_hashes, q->n_slots * nh * 8));
+    HIPCHK(launch_hash_terms(q->d_seq, q->d_qd, q->d_blkq, q->n_slots, q->k, canon, nh, q->d_hashes, g_ctx.stream));
+    q->hash_canon = canon; q->hash_nh = nh;
+    return PM_OK;
+}
+
+extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out) {
+    NEED_DEV();
+    if (!q || !out || num_hashes == 0) return fail(PM_EINVAL, "bad argument");
+    q->hash_canon = -1;   // force a fresh kernel run
+    int rc = ensure_hashes(q, canonicalize ? 1 : 0, num_hashes);
+    if (rc) return rc;
+    std::vector<uint64_t> padded((size_t)(q->n_slots * num_hashes));
+    if (!padded.empty())
+        HIPCHK(hipMemcpyAsync(padded.data(), q->d_hashes, padded.size() * 8, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIPCHK(hipStreamSynchronize(g_ctx.stream));
+    uint64_t o = 0;
+    for (size_t i = 0; i < q->n_terms.size(); ++i) {
+        const uint64_t b0 = q->qd[i].pad_blk;
+        for (uint32_t t = 0; t < q->n_terms[i]; ++t)
+            for (uint32_t j = 0; j < num_hashes; ++j)
+                out[o++] = padded[(size_t)(((b0 + t / 8) * num_hashes + j) * 8 + (t & 7))];
+    }
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------- search
+extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+                         double threshold, uint32_t slot_base, pm_result_t** out) {
+    NEED_DEV();
+    if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
+    if (!(threshold >= 0.0)) return fail(PM_EINVAL, "threshold must be >= 0");
+    for (size_t s = 0; s < n_idx; ++s) {
+        if (!idx[s] || !idx[s]->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
+        if (idx[s]->info.term_size != q->k)
+            return fail(PM_EINVAL, "index %zu has term_size %u but the queries were parsed for %u", s, idx[s]->info.term_size, q->k);
+    }
+    const size_t nq = q->headers.size();
+    pm_result* r = new pm_result();
+    r->st.n_queries = nq; r->st.n_terms = q->total_terms;
+    hipStream_t st = g_ctx.stream;
+
+    // per-query minimum score
+    std::vector<uint32_t> thr(nq);
+    for (size_t i = 0; i < nq; ++i) thr[i] = threshold == 0.0 ? 0u : pm_threshold_terms(threshold, q->n_terms[i]);
+    uint32_t* d_thr = nullptr; uint32_t* d_rows = nullptr; unsigned long long* d_cnt = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    std::vector<hipEvent_t> sev;
+    uint32_t max_nh = 1;
+    for (size_t s = 0; s < n_idx; ++s) max_nh = std::max(max_nh, idx[s]->info.num_hashes);
+    int rc = PM_OK;
+    auto cleanup = [&]() {
+        if (d_thr) hipFree(d_thr);
+        if (d_rows) hipFree(d_rows);
+        if (d_cnt) hipFree(d_cnt);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (ev2) hipEventDestroy(ev2);
+        for (auto e : sev) hipEventDestroy(e);
+    };
+#define SCHK(expr)                                                                         \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            cleanup(); pm_result_free(r);                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                  \
+    } while (0)
+    SCHK(hipMalloc((void**)&d_thr, std::max<size_t>(nq, 1) * 4));
+    SCHK(hipMalloc((void**)&d_rows, std::max<uint64_t>(q->n_slots * max_nh, 8) * 4));
+    SCHK(hipMalloc((void**)&d_cnt, 8));
+    SCHK(hipEventCreate(&ev0)); SCHK(hipEventCreate(&ev1)); SCHK(hipEventCreate(&ev2));
+    sev.resize(n_idx * 2, nullptr);
+    for (auto& e : sev) SCHK(hipEventCreate(&e));
+    if (nq) SCHK(hipMemcpyAsync(d_thr, thr.data(), nq * 4, hipMemcpyHostToDevice, st));
+
+    r->cap = std::max<uint64_t>(1u << 20, (uint64_t)nq * 16);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SCHK(hipMalloc((void**)&r->d_hits, r->cap * sizeof(uint4)));
+        SCHK(hipMemsetAsync(d_cnt, 0, 8, st));
+        SCHK(hipEventRecord(ev0, st));
+        uint64_t alg = 0;
+        // hashes are recomputed by every pm_search call (one job = hash + scan);
+        // within the call they are shared by all indexes with equal (canonicalize, num_hashes)
+        q->hash_canon = -1;
+        rc = ensure_hashes(q, (int)idx[0]->info.canonicalize, idx[0]->info.num_hashes);
+        if (rc) { cleanup(); pm_result_free(r); return rc; }
+        SCHK(hipEventRecord(ev1, st));
+        for (size_t s = 0; s < n_idx; ++s) {
+            const pm_index* ix = idx[s];
+            const int canon = (int)ix->info.canonicalize; const uint32_t nh = ix->info.num_hashes;
+            rc = ensure_hashes(q, canon, nh);
+            if (rc) { cleanup(); pm_result_free(r); return rc; }
+            SCHK(launch_map_rows(q->d_hashes, q->n_slots * nh, ix->info.signature_size, d_rows, st));
+            SCHK(hipEventRecord(sev[2 * s], st));
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
+                if (e == b) continue;
+                ScanArgs a;
+                a.matrix = ix->d_matrix; a.stride = ix->info.stride; a.rows = d_rows;
+                a.qd = q->d_qd; a.thr = d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
+                a.n_docs = ix->info.n_docs; a.nh = nh; a.slot = slot_base + (uint32_t)s;
+                a.hits = r->d_hits; a.hit_count = d_cnt; a.hit_cap = r->cap;
+                SCHK(launch_scan(a, ix->g, kPlaneClass[c], ix->slabs, st));
+                r->st.n_scan_launches += 1;
+            }
+            SCHK(hipEventRecord(sev[2 * s + 1], st));
+            alg += q->total_terms * nh * ix->info.row_bytes;
+        }
+        SCHK(hipEventRecord(ev2, st));
+        unsigned long long cnt = 0;
+        SCHK(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        SCHK(hipStreamSynchronize(st));
+        r->st.algorithmic_bytes = alg;
+        if (cnt <= r->cap) {
+            r->n_hits = cnt;
+            float ms = 0;
+            SCHK(hipEventElapsedTime(&ms, ev0, ev2)); r->st.ms_total = ms;
+            SCHK(hipEventElapsedTime(&ms, ev0, ev1)); r->st.ms_hash = ms;
+            double scan = 0;
+            for (size_t s = 0; s < n_idx; ++s) { SCHK(hipEventElapsedTime(&ms, sev[2 * s], sev[2 * s + 1])); scan += ms; }
+            r->st.ms_scan = scan;
+            break;
+        }
+        // hit buffer too small: grow to the exact count and run again
+        if (attempt == 1) { cleanup(); pm_result_free(r); return fail(PM_EHIP, "hit count changed between runs"); }
+        hipFree(r->d_hits); r->d_hits = nullptr;
+        r->cap = cnt;
+        r->st.n_scan_launches = 0;
+    }
+#undef SCHK
+    r->st.n_hits = r->n_hits;
+    cleanup();
+    *out = r;
+    return PM_OK;
+}
+
+extern "C" int pm_result_stats(const pm_result_t* r, pm_stats_t* st) {
+    if (!r || !st) return fail(PM_EINVAL, "bad argument");
+    *st = r->st;
+    return PM_OK;
+}
+extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n) {
+    if (!r || !dptr || !n) return fail(PM_EINVAL, "bad argument");
+    *dptr = r->d_hits; *n = r->n_hits;
+    return PM_OK;
+}
+extern "C" int pm_result_copy_hits_device(const pm_result_t* r, void* dst, uint64_t capacity) {
+    NEED_DEV();
+    if (!r || (!dst && r->n_hits)) return fail(PM_EINVAL, "bad argument");
+    if (capacity < r->n_hits) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
+                                          (unsigned long long)capacity, (unsigned long long)r->n_hits);
+    if (r->n_hits) {
+        HIPCHK(hipMemcpyAsync(dst, r->d_hits, r->n_hits * sizeof(uint4), hipMemcpyDeviceToDevice, g_ctx.stream));
+        HIPCHK(hipStreamSynchronize(g_ctx.stream));
+    }
+    return PM_OK;
+}
+
+static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
+    if (a.slot != b.slot) return a.slot < b.slot;
+    if (a.query != b.query) return a.query < b.query;
+    if (a.score != b.score) return a.score > b.score;     // score descending
+    return a.doc < b.doc;                                 // then document index ascending
+}
+
+extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {
+    NEED_DEV();
+    if (!r || !hits || !n) return fail(PM_EINVAL, "bad argument");
+    if (!r->host_ready) {
+        r->host.resize((size_t)r->n_hits);
+        if (r->n_hits) {
+            HIPCHK(hipMemcpyAsync(r->host.data(), r->d_hits, r->n_hits * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.stream));
+            HIPCHK(hipStreamSynchronize(g_ctx.stream));
+        }
+        std::sort(r->host.begin(), r->host.end(), hit_less);
+        r->host_ready = true;
+    }
+    *hits = r->host.data(); *n = r->n_hits;
+    return PM_OK;
+}
+extern "C" void pm_result_free(pm_result_t* r) {
+    if (!r) return;
+    if (r->d_hits) hipFree(r->d_hits);
+    delete r;
+}
+
+// --------------------------------------------------------------------- text
+// cobs stdout grammar (witnesses: scripts/postprocess_cobs.py:23-26, :10-13;
+// scripts/filter_queries.py:51-65): "*<header>\t<N>\n" then N lines
+// "<doc name>\t<score>\n", best score first, ties by document index.
+// nb_best_hits >= 0 fuses scripts/postprocess_cobs.py:16-39: header untouched,
+// each name cut to "_" + what follows its first '_', the first n lines kept plus
+// later lines whose score equals the n-th score.
+extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
+                              const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                              int64_t nb_best, char** text, size_t* len) {
+    if (!ix || !q || (!hits && n_hits) || !text || !len) return fail(PM_EINVAL, "bad argument");
+    const size_t nq = q->headers.size();
+    std::vector<pm_hit_t> mine;
+    for (uint64_t i = 0; i < n_hits; ++i) if (hits[i].slot == slot) mine.push_back(hits[i]);
+    for (const pm_hit_t& h : mine)
+        if (h.query >= nq || h.doc >= ix->info.n_docs)
+            return fail(PM_EINVAL, "hit record (query %u, doc %u) out of range for this index/query set", h.query, h.doc);
+    std::sort(mine.begin(), mine.end(), hit_less);
+    std::string out;
+    out.reserve(mine.size() * 24 + nq * 24);
+    char num[32];
+    size_t p = 0;
+    for (size_t qi = 0; qi < nq; ++qi) {
+        size_t e = p;
+        while (e < mine.size() && mine[e].query == qi) ++e;
+        out.push_back('*'); out += q->headers[qi];
+        out.append(num, (size_t)snprintf(num, sizeof num, "\t%zu\n", e - p));
+        uint32_t min_kmers = 0;
+        for (size_t i = p; i < e; ++i) {
+            const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
+            const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
+            if (nb_best < 0) {
+                out.append(nm, nl);
+                out.append(num, (size_t)snprintf(num, sizeof num, "\t%u\n", mine[i].score));
+                continue;
+            }
+            const int64_t rank = (int64_t)(i - p) + 1;      // 1-based like the post-filter's counter
+            const char* us = (const char*)memchr(nm, '_', nl);
+            if (!us) {
+                // postprocess_cobs.py:16-18 turns such a line into a bare "_" (no newline) and
+                // raises on int("_") once rank >= n: an error for the whole rule
+                if (rank < nb_best) { out.push_back('_'); continue; }
+                return fail(PM_EINVAL, "document name '%.*s' has no '_' separator (post-filter cannot parse it)", (int)nl, nm);
+            }
+            bool keep;
+            if (rank < nb_best) keep = true;
+            else if (rank == nb_best) { keep = true; min_kmers = mine[i].score; }
+            else keep = mine[i].score == min_kmers;
+            if (keep) {
+                out.append(us, nl - (size_t)(us - nm));
+                out.append(num, (size_t)snprintf(num, sizeof num, "\t%u\n", mine[i].score));
+            }
+        }
+        p = e;
+    }
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
+    *text = buf; *len = out.size();
+    return PM_OK;
+}
+
+extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len,
+                             double threshold, int64_t nb_best, char** text, size_t* len) {
+    NEED_DEV();
+    if (!ix) return fail(PM_EINVAL, "bad argument");
+    pm_queries_t* q = nullptr; pm_result_t* r = nullptr;
+    int rc = pm_queries_parse(fasta, fasta_len, ix->info.term_size, &q);
+    if (rc) return rc;
+    uint64_t nq = 0; pm_queries_count(q, &nq, nullptr);
+    const pm_hit_t* hits = nullptr; uint64_t n = 0;
+    if (nq) {
+        pm_index_t* arr[1] = {ix};
+        rc = pm_search(arr, 1, q, threshold, 0, &r);
+        if (rc == PM_OK) rc = pm_result_hits_host(r, &hits, &n);
+    }
+    if (rc == PM_OK) rc = pm_format_hits(ix, q, hits, n, 0, nb_best, text, len);
+    if (r) pm_result_free(r);
+    pm_queries_free(q);
+    return rc;
+}

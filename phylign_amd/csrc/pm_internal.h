@@ -1,0 +1,48 @@
+// pm_internal.h -- shared between pm_host.cpp (host orchestration) and
+// pm_kernels.hip (gfx950 kernels).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pm {
+
+// Per-query descriptor in HBM (16 B).  Terms of a query live in 8-slot blocks
+// starting at block `pad_blk`; slots past n_terms are padding.
+struct QDesc {
+    uint32_t n_terms;
+    uint32_t pad_blk;
+    uint32_t seq_lo, seq_hi;   // byte offset of the sequence in the packed buffer
+};
+
+struct ScanArgs {
+    const uint8_t*  matrix;     // row r at matrix + r*stride, 16-B aligned
+    uint64_t        stride;
+    const uint32_t* rows;       // [blk][hash j][8] row indices of this batch
+    const QDesc*    qd;
+    const uint32_t* thr;        // per query minimum score (0 = keep all)
+    const uint32_t* qmap;       // launch-local index -> query id
+    uint32_t        nq;         // queries in this launch
+    uint32_t        n_docs;
+    uint32_t        nh;
+    uint32_t        slot;
+    uint4*          hits;       // pm_hit_t records
+    unsigned long long* hit_count;
+    uint64_t        hit_cap;
+};
+
+// launchers (pm_kernels.hip); all asynchronous on `st`, return hipError_t
+hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t* blk_query,
+                             uint64_t n_slots, uint32_t k, int canon, uint32_t nh,
+                             uint64_t* hashes, hipStream_t st);
+hipError_t launch_map_rows(const uint64_t* hashes, uint64_t n, uint64_t sig_size,
+                           uint32_t* rows, hipStream_t st);
+// g = lanes per row (1..64 pow2), planes = counter bit planes (7,10,16,24)
+hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st);
+hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst, uint64_t stride,
+                           uint64_t n_rows, hipStream_t st);
+hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs,
+                        uint64_t seed, uint32_t batch, hipStream_t st);
+hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
+                        uint64_t n, hipStream_t st);
+
+}  // namespace pm

@@ -1,0 +1,427 @@
+// pm_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the COBS matching stage.
+//
+// Replaces the hot loop of the external `cobs query` binary the reference calls
+// at scripts/run_cobs_streaming.sh:24-29 / Snakefile:419-424 (SURVEY.md 8a rows
+// a5-a7).  Written for 64-wide wavefronts; no MFMA on purpose: the path is a
+// random row gather plus bit-sliced counting, bounded by HBM.
+//
+//   k_hash_terms  a5  canonicalise each k-mer + XXH64(seed j)
+//   k_map_rows    a5  row = hash % signature_size (Barrett, exact)
+//   k_scan        a6  gather rows (16 B per lane, G lanes per row), AND over
+//                     hash functions, carry-save bit-sliced per-document counts
+//                 a7  bit-sliced ">= threshold", ballot/mbcnt compaction of hits
+//   k_restride / k_synth / k_plant   index residency helpers (a4)
+#include "pm_internal.h"
+
+namespace pm {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ hashing
+#define XP1 0x9E3779B185EBCA87ULL
+#define XP2 0xC2B2AE3D27D4EB4FULL
+#define XP3 0x165667B19E3779F9ULL
+#define XP4 0x85EBCA77C2B2AE63ULL
+#define XP5 0x27D4EB2F165667C5ULL
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) {
+    acc += in * XP2; acc = rotl64(acc, 31); return acc * XP1;
+}
+__device__ __forceinline__ uint64_t xmerge(uint64_t acc, uint64_t v) {
+    v = xround(0, v); acc ^= v; return acc * XP1 + XP4;
+}
+// A<->T, C<->G on upper-case ASCII: A/T have bit1 clear (xor 0x15), C/G set (xor 0x04)
+__device__ __forceinline__ uint32_t comp_base(uint32_t c) { return c ^ ((c & 2u) ? 0x04u : 0x15u); }
+
+// Byte i of the canonical form of the k-mer at p (rc: reverse complement chosen).
+struct KmerView {
+    const uint8_t* p; uint32_t k; bool rc;
+    __device__ __forceinline__ uint64_t byte(uint32_t i) const {
+        return rc ? (uint64_t)comp_base(p[k - 1 - i]) : (uint64_t)p[i];
+    }
+    __device__ __forceinline__ uint64_t le64(uint32_t i) const {
+        uint64_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v |= byte(i + b) << (8 * b);
+        return v;
+    }
+};
+
+__device__ uint64_t xxh64_kmer(const KmerView& kv, uint64_t seed) {
+    const uint32_t len = kv.k;
+    uint32_t i = 0;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        do {
+            v1 = xround(v1, kv.le64(i));      v2 = xround(v2, kv.le64(i + 8));
+            v3 = xround(v3, kv.le64(i + 16)); v4 = xround(v4, kv.le64(i + 24));
+            i += 32;
+        } while (i + 32 <= len);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = seed + XP5;
+    }
+    h += (uint64_t)len;
+    while (i + 8 <= len) { h ^= xround(0, kv.le64(i)); h = rotl64(h, 27) * XP1 + XP4; i += 8; }
+    if (i + 4 <= len) {
+        uint64_t w = kv.byte(i) | (kv.byte(i + 1) << 8) | (kv.byte(i + 2) << 16) | (kv.byte(i + 3) << 24);
+        h ^= w * XP1; h = rotl64(h, 23) * XP2 + XP3; i += 4;
+    }
+    while (i < len) { h ^= kv.byte(i) * XP5; h = rotl64(h, 11) * XP1; ++i; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
+
+// One thread per padded term slot.  hashes layout: [8-slot block][hash j][8].
+__global__ __launch_bounds__(256) void k_hash_terms(
+    const uint8_t* __restrict__ seq, const QDesc* __restrict__ qd,
+    const uint32_t* __restrict__ blk_query, uint64_t n_slots, uint32_t k, int canon,
+    uint32_t nh, uint64_t* __restrict__ hashes)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const uint64_t blk = s >> 3;
+    const QDesc d = qd[blk_query[blk]];
+    const uint32_t t = (uint32_t)(s - (uint64_t)d.pad_blk * 8);
+    uint64_t* out = hashes + blk * nh * 8 + (s & 7);
+    if (t >= d.n_terms) {
+        for (uint32_t j = 0; j < nh; ++j) out[j * 8] = 0;
+        return;
+    }
+    KmerView kv;
+    kv.p = seq + (((uint64_t)d.seq_hi << 32) | d.seq_lo) + t;
+    kv.k = k; kv.rc = false;
+    if (canon) {
+        // lexicographic min(kmer, revcomp): first position where they differ decides
+        for (uint32_t i = 0; i < k; ++i) {
+            const uint32_t f = kv.p[i], r = comp_base(kv.p[k - 1 - i]);
+            if (f != r) { kv.rc = r < f; break; }
+        }
+    }
+    for (uint32_t j = 0; j < nh; ++j) out[j * 8] = xxh64_kmer(kv, (uint64_t)j);
+}
+
+// row = h % S, exact: Barrett with m = floor(2^64 / S) and at most two fix-ups.
+__global__ __launch_bounds__(256) void k_map_rows(
+    const uint64_t* __restrict__ hashes, uint64_t n, uint64_t S, uint64_t m,
+    uint32_t* __restrict__ rows)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = hashes[i];
+    uint64_t r;
+    if (S == 1) r = 0;
+    else {
+        const uint64_t qh = __umul64hi(h, m);
+        r = h - qh * S;
+        while (r >= S) r -= S;
+    }
+    rows[i] = (uint32_t)r;
+}
+
+// --------------------------------------------------------------------- scan
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// carry-save adder on 128 document columns: (s, c) = a + b + cin bitwise
+#define PM_CSA(s, c, a, b, cin)                         \
+    do {                                                \
+        const u32x4 u_ = (a) ^ (b);                     \
+        const u32x4 a_ = (a);                           \
+        const u32x4 ci_ = (cin);                        \
+        (s) = u_ ^ ci_;                                 \
+        (c) = (u_ & ci_) | (~u_ & a_);                  \
+    } while (0)
+
+// G lanes cooperate on one query (16 B = 128 documents per lane); a wave holds
+// 64/G queries; P = number of counter bit planes (queries with < 2^P terms).
+template <int G, int P, bool NH1>
+__global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
+{
+    constexpr int QPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t li = (blockIdx.x * 4u + (uint32_t)wave) * QPW + (uint32_t)(lane / G);
+    const uint32_t c = (uint32_t)(lane % G);
+    const uint32_t slab = blockIdx.y;
+    const uint64_t boff = ((uint64_t)slab * G + c) * 16;   // byte offset of this lane's chunk
+    const bool qv = li < a.nq;
+
+    uint32_t q = 0, nt = 0, thr = 0;
+    uint64_t pb = 0;
+    if (qv) {
+        q = a.qmap[li];
+        const QDesc d = a.qd[q];
+        nt = d.n_terms; pb = d.pad_blk; thr = a.thr[q];
+    }
+    const bool active = qv && boff < a.stride;
+    const uint32_t nblk = active ? (nt + 7u) >> 3 : 0u;
+    const uint32_t wmax = wave_max_u32(nblk);
+    const uint32_t nh = NH1 ? 1u : a.nh;
+
+    const uint8_t* base = a.matrix + boff;
+    const u32x4* ridx = reinterpret_cast<const u32x4*>(a.rows + pb * nh * 8);
+    const uint64_t stride = a.stride;
+
+    u32x4 pl[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) pl[p] = (u32x4)(0u);
+
+    for (uint32_t b = 0; b < wmax; ++b) {
+        u32x4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = (u32x4)(0u);
+        if (b < nblk) {
+            const uint32_t left = nt - b * 8u;        // >= 1 valid terms in this block
+            for (uint32_t j = 0; j < nh; ++j) {
+                const u32x4 i0 = ridx[(b * nh + j) * 2 + 0];
+                const u32x4 i1 = ridx[(b * nh + j) * 2 + 1];
+                const uint32_t r[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+                u32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = (u32x4)(0u);
+                    if ((uint32_t)i < left)
+                        v[i] = *reinterpret_cast<const u32x4*>(base + (uint64_t)r[i] * stride);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = (j == 0) ? v[i] : (x[i] & v[i]);
+            }
+        }
+        // 8 one-bit inputs -> ones/twos/fours planes + one carry of weight 8
+        u32x4 t0, t1, t2, t3, f0, f1, e0;
+        PM_CSA(pl[0], t0, pl[0], x[0], x[1]);
+        PM_CSA(pl[0], t1, pl[0], x[2], x[3]);
+        PM_CSA(pl[1], f0, pl[1], t0, t1);
+        PM_CSA(pl[0], t2, pl[0], x[4], x[5]);
+        PM_CSA(pl[0], t3, pl[0], x[6], x[7]);
+        PM_CSA(pl[1], f1, pl[1], t2, t3);
+        PM_CSA(pl[2], e0, pl[2], f0, f1);
+#pragma unroll
+        for (int p = 3; p < P; ++p) {
+            const u32x4 t = pl[p] & e0;
+            pl[p] ^= e0;
+            e0 = t;
+        }
+    }
+
+    // ---- a7: score >= thr, bit-sliced.  carry-out of score + (2^P - thr).
+    u32x4 mask;
+    if (thr == 0u) mask = (u32x4)(0xFFFFFFFFu);
+    else if (thr > nt) mask = (u32x4)(0u);
+    else {
+        const uint32_t K = (1u << P) - thr;
+        u32x4 cy = (u32x4)(0u);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const u32x4 both = pl[p] & cy, any = pl[p] | cy;
+            cy = ((K >> p) & 1u) ? any : both;
+        }
+        mask = cy;
+    }
+    // drop columns >= n_docs (row padding) and inactive lanes
+    const uint64_t doc0 = ((uint64_t)slab * G + c) * 128;
+    uint32_t mw[4] = {mask.x, mask.y, mask.z, mask.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t first = doc0 + 32u * w;
+        uint32_t keep;
+        if (!active || first >= a.n_docs) keep = 0u;
+        else if (first + 32 > a.n_docs) keep = (1u << (a.n_docs - first)) - 1u;
+        else keep = 0xFFFFFFFFu;
+        mw[w] &= keep;
+    }
+
+    // ---- compaction: every round each lane with a pending hit pops one bit;
+    // ballot + mbcnt rank the writers, one atomic per wave per round.
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t m = mw[w];
+        while (true) {
+            const bool has = m != 0u;
+            const unsigned long long bal = __ballot(has);
+            if (bal == 0ull) break;
+            uint32_t doc = 0, score = 0;
+            if (has) {
+                const int bit = __ffs((int)m) - 1;
+                m &= m - 1u;
+                doc = (uint32_t)(doc0 + 32u * w + (uint32_t)bit);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const uint32_t word = (w == 0) ? pl[p].x : (w == 1) ? pl[p].y : (w == 2) ? pl[p].z : pl[p].w;
+                    score |= ((word >> bit) & 1u) << p;
+                }
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            const uint32_t tot = (uint32_t)__popcll(bal);
+            unsigned long long basev = 0;
+            if (lane == (int)(__ffsll((long long)bal) - 1))
+                basev = atomicAdd(a.hit_count, (unsigned long long)tot);
+            const uint32_t src = (uint32_t)(__ffsll((long long)bal) - 1);
+            const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, (int)src, 64);
+            const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), (int)src, 64);
+            const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
+            if (has && pos < a.hit_cap) a.hits[pos] = make_uint4(q, doc, score, a.slot);
+        }
+    }
+}
+
+template <int G, int P>
+static hipError_t scan_dispatch_nh(const ScanArgs& a, uint32_t slabs, hipStream_t st) {
+    constexpr int QPB = 4 * (64 / G);
+    dim3 grid((a.nq + QPB - 1) / QPB, slabs, 1);
+    if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true>), grid, dim3(256), 0, st, a);
+    else           hipLaunchKernelGGL((k_scan<G, P, false>), grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+template <int G>
+static hipError_t scan_dispatch_p(const ScanArgs& a, int planes, uint32_t slabs, hipStream_t st) {
+    switch (planes) {
+        case 7:  return scan_dispatch_nh<G, 7>(a, slabs, st);
+        case 10: return scan_dispatch_nh<G, 10>(a, slabs, st);
+        case 16: return scan_dispatch_nh<G, 16>(a, slabs, st);
+        case 24: return scan_dispatch_nh<G, 24>(a, slabs, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st) {
+    if (a.nq == 0) return hipSuccess;
+    switch (g) {
+        case 1:  return scan_dispatch_p<1>(a, planes, slabs, st);
+        case 2:  return scan_dispatch_p<2>(a, planes, slabs, st);
+        case 4:  return scan_dispatch_p<4>(a, planes, slabs, st);
+        case 8:  return scan_dispatch_p<8>(a, planes, slabs, st);
+        case 16: return scan_dispatch_p<16>(a, planes, slabs, st);
+        case 32: return scan_dispatch_p<32>(a, planes, slabs, st);
+        case 64: return scan_dispatch_p<64>(a, planes, slabs, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t* blk_query,
+                             uint64_t n_slots, uint32_t k, int canon, uint32_t nh,
+                             uint64_t* hashes, hipStream_t st) {
+    if (n_slots == 0) return hipSuccess;
+    const uint64_t blocks = (n_slots + 255) / 256;
+    hipLaunchKernelGGL(k_hash_terms, dim3((uint32_t)blocks), dim3(256), 0, st,
+                       seq, qd, blk_query, n_slots, k, canon, nh, hashes);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_rows(const uint64_t* hashes, uint64_t n, uint64_t S, uint32_t* rows, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    // m = floor(2^64 / S) for S >= 2
+    uint64_t m = 0;
+    if (S >= 2) {
+        m = ~0ull / S;
+        if ((~0ull % S) + 1 == S) m += 1;   // 2^64 = (2^64-1) + 1
+    }
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_map_rows, dim3((uint32_t)blocks), dim3(256), 0, st, hashes, n, S, m, rows);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------- index helpers
+// dst row r = src row r (row_bytes) followed by zero padding up to stride.
+__global__ __launch_bounds__(256) void k_restride(
+    const uint8_t* __restrict__ src, uint64_t row_bytes, uint8_t* __restrict__ dst,
+    uint64_t stride, uint64_t n_rows)
+{
+    const uint64_t chunks_per_row = stride >> 4;
+    const uint64_t total = n_rows * chunks_per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / chunks_per_row, ch = i - r * chunks_per_row;
+        const uint64_t b0 = ch * 16;
+        const uint8_t* s = src + r * row_bytes + b0;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            if (b0 + b < row_bytes) w[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
+        *reinterpret_cast<uint4*>(dst + r * stride + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst, uint64_t stride,
+                           uint64_t n_rows, hipStream_t st) {
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t total = n_rows * (stride >> 4);
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_restride, dim3((uint32_t)blocks), dim3(256), 0, st, src, row_bytes, dst, stride, n_rows);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+// Synthetic 661k-shaped matrix: dword j of row r = lo32(u) & hi32(u),
+// u = splitmix64(splitmix64(splitmix64(seed ^ batch*C) + r) + j): P(bit)=1/4.
+__global__ __launch_bounds__(256) void k_synth(
+    uint8_t* __restrict__ dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs, uint64_t kb)
+{
+    const uint64_t chunks_per_row = stride >> 4;
+    const uint64_t total = n_rows * chunks_per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / chunks_per_row, ch = i - r * chunks_per_row;
+        const uint64_t kr = splitmix64(kb + r);
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t j = ch * 4 + k;
+            const uint64_t first_doc = j * 32;
+            uint32_t v = 0;
+            if (first_doc < n_docs) {
+                const uint64_t u = splitmix64(kr + j);
+                v = (uint32_t)u & (uint32_t)(u >> 32);
+                if (first_doc + 32 > n_docs) v &= (1u << (n_docs - first_doc)) - 1u;
+            }
+            w[k] = v;
+        }
+        *reinterpret_cast<uint4*>(dst + r * stride + ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs,
+                        uint64_t seed, uint32_t batch, hipStream_t st) {
+    if (n_rows == 0) return hipSuccess;
+    // kb = splitmix64(seed ^ batch * C) computed on the host side of the launcher
+    uint64_t x = seed ^ ((uint64_t)batch * 0xD1B54A32D192ED03ULL);
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    const uint64_t kb = x ^ (x >> 31);
+    const uint64_t total = n_rows * (stride >> 4);
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL(k_synth, dim3((uint32_t)blocks), dim3(256), 0, st, dst, stride, n_rows, n_docs, kb);
+    return hipGetLastError();
+}
+
+__global__ void k_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = docs[i];
+    uint32_t* w = reinterpret_cast<uint32_t*>(matrix + rows[i] * stride + (uint64_t)(d >> 5) * 4);
+    atomicOr(w, 1u << (d & 31));
+}
+hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
+                        uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_plant, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, matrix, stride, rows, docs, n);
+    return hipGetLastError();
+}
+
+}  // namespace pm

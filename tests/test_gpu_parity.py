@@ -1,0 +1,214 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle, bit-exact.
+Reference path: `cobs query` as called at scripts/run_cobs_streaming.sh:24-29."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import build_case, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,canon,nh", [(31, 1, 1), (31, 0, 1), (31, 1, 3), (15, 1, 2), (32, 1, 1),
+                                         (33, 0, 2), (45, 1, 1), (64, 1, 1), (71, 1, 2), (4, 1, 1)])
+def test_hash_parity(pm, oracle, k, canon, nh):
+    rng = np.random.default_rng(100 + k + canon + nh)
+    seqs = [rand_seq(rng, int(n)) for n in list(rng.integers(k, k + 300, size=40)) + [k, k + 1, k + 7, k + 8, k + 9]]
+    seqs.append("A" * (k + 5))
+    seqs.append(("ACGT" * 40)[: k + 20])  # revcomp palindromes (ACGT) for even k
+    fasta = "".join(f">q{i}\n{s}\n" for i, s in enumerate(seqs)).encode()
+    q = pm.Queries(fasta, term_size=k)
+    got = q.hash_terms(canonicalize=canon, num_hashes=nh)
+    exp = np.concatenate([oracle.create_hashes(s.encode(), k, canon, nh) for s in seqs])
+    assert got.dtype == np.uint64 and got.shape == exp.shape
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("n_docs", [1, 8, 13, 100, 129, 664, 1300, 4000, 9001])
+def test_index_roundtrip(pm, oracle, layout, n_docs):
+    rng = np.random.default_rng(n_docs)
+    S = 777
+    index, _, matrix = build_case(oracle, rng, n_docs, S, [("q", rand_seq(rng, 40))])
+    ix = pm.Index.load_mem(index, layout=layout)
+    info = ix.info
+    assert (info.n_docs, info.signature_size, info.term_size, info.canonicalize, info.num_hashes) == (n_docs, S, 31, 1, 1)
+    assert info.row_bytes == (n_docs + 7) // 8 and info.stride >= info.row_bytes and info.stride % 16 == 0
+    for r in [0, 1, S // 2, S - 1]:
+        assert np.array_equal(ix.read_row(r), matrix[r])
+    h = oracle.header_parse(index)
+    assert ix.doc_name(0) == bytes(index[h.names_off:]).split(b"\n")[0].decode()
+
+
+CASES = [
+    # n_docs, sig, nq, qlen, k, canon, nh, threshold
+    (5, 500, 12, 150, 31, 1, 1, 0.7),
+    (64, 3000, 30, 150, 31, 1, 1, 0.7),
+    (100, 3000, 30, 100, 31, 1, 2, 0.5),
+    (130, 2000, 25, 150, 31, 0, 1, 0.7),
+    (195, 4000, 40, 150, 31, 1, 1, 0.7),
+    (664, 5000, 40, 150, 31, 1, 1, 0.7),
+    (1000, 2000, 20, 60, 21, 1, 3, 0.3),
+    (2300, 3000, 24, 150, 31, 1, 1, 0.7),
+    (4000, 4000, 33, 150, 31, 1, 1, 0.7),
+    (9001, 1500, 9, 150, 31, 1, 1, 0.7),
+    (17000, 700, 5, 90, 31, 1, 2, 0.6),
+    (664, 5000, 20, 31, 31, 1, 1, 0.7),     # one k-mer per query: hit <=> bit set
+    (300, 2000, 16, 150, 31, 1, 1, 0.0),    # threshold 0 keeps every document
+    (300, 2000, 16, 150, 31, 1, 1, 1.0),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "D%d_S%d_q%dx%d_k%d_c%d_h%d_t%s" % c)
+@pytest.mark.parametrize("layout", [1, 2])
+def test_query_text_bit_exact(pm, oracle, case, layout):
+    n_docs, S, nq, qlen, k, canon, nh, thr = case
+    rng = np.random.default_rng(hash(case) % (2**32))
+    queries = [(f"read{i} comment {i}" if i % 3 == 0 else f"read{i}", rand_seq(rng, qlen)) for i in range(nq)]
+    plant = []
+    for qi in range(0, nq, 2):
+        for frac in (1.0, 0.8, 0.7, 0.69, 0.6, 0.71):
+            plant.append((qi, int(rng.integers(0, n_docs)), frac))
+        # tie group: several docs at the same planted fraction
+        for d in rng.integers(0, n_docs, size=3):
+            plant.append((qi, int(d), 0.75))
+    index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, k=k, canon=canon, num_hashes=nh, plant=plant)
+    exp = oracle.query_file(index, fasta, thr)
+    ix = pm.Index.load_mem(index, layout=layout)
+    got = pm.query_text(ix, fasta, thr)
+    assert got == exp
+    assert got.count(b"*") == nq
+
+
+def test_mixed_lengths_and_plane_classes(pm, oracle):
+    """queries of 1..70k k-mers in one FASTA: every counter-width class (7/10/16/24 planes)."""
+    rng = np.random.default_rng(5)
+    lens = [31, 32, 100, 157, 158, 160, 400, 1053, 1054, 3000, 65565, 65566, 70000, 150, 31]
+    queries = [(f"g{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
+    plant = [(i, int(rng.integers(0, 200)), f) for i in range(len(lens)) for f in (1.0, 0.7, 0.5)]
+    index, fasta, _ = build_case(oracle, rng, 200, 9000, queries, plant=plant, density=0.3)
+    ix = pm.Index.load_mem(index)
+    for thr in (0.7, 0.28):
+        assert pm.query_text(ix, fasta, thr) == oracle.query_file(index, fasta, thr)
+
+
+def test_fasta_record_rules(pm, oracle):
+    rng = np.random.default_rng(6)
+    s = [rand_seq(rng, 90) for _ in range(4)]
+    fasta = (f"\n>a first\n{s[0][:40]}\n{s[0][40:]}\n\n;b semicolon header\n{s[1]}\n>empty\n>c\n{s[2]}\n>d\tTAB\n{s[3]}").encode()
+    index, _, _ = build_case(oracle, rng, 77, 1000, [("a", s[0]), ("b", s[1]), ("c", s[2])],
+                             plant=[(0, 3, 1.0), (1, 70, 0.9), (2, 76, 0.8)])
+    ix = pm.Index.load_mem(index)
+    got = pm.query_text(ix, fasta, 0.7)
+    assert got == oracle.query_file(index, fasta, 0.7)
+    assert got.startswith(b"*a first\t") and b"*empty" not in got and b"*b semicolon header\t" in got
+    assert pm.query_text(ix, b"", 0.7) == b"" == oracle.query_file(index, b"", 0.7)
+
+
+def test_query_errors(pm, oracle):
+    rng = np.random.default_rng(7)
+    index, _, _ = build_case(oracle, rng, 20, 100, [("a", rand_seq(rng, 50))])
+    ix = pm.Index.load_mem(index)
+    with pytest.raises(pm.PMError) as e:
+        pm.query_text(ix, b">short\nACGTACGT\n", 0.7)
+    assert e.value.code == -6
+    with pytest.raises(pm.PMError) as e:
+        pm.query_text(ix, (">n\n" + "ACGTN" * 10 + "\n").encode(), 0.7)
+    assert e.value.code == -6
+    with pytest.raises(pm.PMError) as e:
+        pm.Index.load_mem(b"COBS:NOT_AN_INDEX" + bytes(100))
+    assert e.value.code == -5
+    with pytest.raises(pm.PMError) as e:
+        pm.Index.load_mem(bytes(index[: len(index) - 10]))
+    assert e.value.code == -4
+
+
+def test_streaming_pipe_load(pm, oracle, tmp_path):
+    """index arrives on a non-seekable pipe with --index-sizes (run_cobs_streaming.sh:27-28)."""
+    import threading
+    rng = np.random.default_rng(8)
+    queries = [(f"r{i}", rand_seq(rng, 150)) for i in range(10)]
+    index, fasta, _ = build_case(oracle, rng, 664, 60000, queries, plant=[(i, i * 7, 0.9) for i in range(10)])
+    r, w = os.pipe()
+
+    def feed():
+        with os.fdopen(w, "wb") as f:
+            b = bytes(index)
+            for o in range(0, len(b), 70001):
+                f.write(b[o:o + 70001])
+    t = threading.Thread(target=feed)
+    t.start()
+    ix = pm.Index.load_fd(r, size_hint=len(index))
+    t.join()
+    os.close(r)
+    assert pm.query_text(ix, fasta, 0.7) == oracle.query_file(index, fasta, 0.7)
+    p = tmp_path / "x.cobs_classic"
+    p.write_bytes(bytes(index))
+    ix2 = pm.Index.load_file(str(p))
+    assert pm.query_text(ix2, fasta, 0.7) == oracle.query_file(index, fasta, 0.7)
+
+
+@pytest.mark.parametrize("n_docs,S,batch", [(664, 5000, 3), (4000, 3000, 0), (195, 4000, 7), (13, 900, 1), (9001, 300, 2)])
+def test_synth_generator_matches_spec(pm, oracle, n_docs, S, batch):
+    ix = pm.Index.synth(batch, n_docs, S, seed=661)
+    for r in [0, 1, 2, S // 3, S - 1]:
+        assert np.array_equal(ix.read_row(r), oracle.synth_row(661, batch, r, n_docs))
+    # density ~ 1/4
+    rows = np.stack([ix.read_row(r) for r in range(0, S, max(1, S // 50))])
+    dens = np.unpackbits(rows, axis=1, bitorder="little")[:, :n_docs].mean()
+    assert 0.2 < dens < 0.3
+
+
+def test_synth_search_with_planted_hits(pm, oracle):
+    """synthetic batch + planted hits vs the oracle evaluated on a virtual matrix."""
+    rng = np.random.default_rng(9)
+    n_docs, S, batch = 664, 200000, 5
+    ix = pm.Index.synth(batch, n_docs, S, seed=661)
+    queries = [(f"s{i}", rand_seq(rng, 150)) for i in range(50)]
+    fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
+    overlay = {}
+    rows, docs = [], []
+    for qi in range(0, 50, 3):
+        hs = oracle.create_hashes(queries[qi][1].encode(), 31, 1, 1)
+        for doc, frac in ((int(rng.integers(0, n_docs)), 1.0), (int(rng.integers(0, n_docs)), 0.7), (int(rng.integers(0, n_docs)), 0.65)):
+            for t in range(int(np.ceil(frac * len(hs)))):
+                r = int(hs[t]) % S
+                rows.append(r); docs.append(doc)
+                overlay.setdefault(r, []).append(doc)
+    ix.plant(rows, docs)
+
+    def row_fn(r):
+        v = oracle.synth_row(661, batch, r, n_docs)
+        for d in overlay.get(r, ()):
+            v[d >> 3] |= np.uint8(1 << (d & 7))
+        return v
+    qobj = pm.Queries(fasta)
+    res = pm.search([ix], qobj, 0.7)
+    hits = res.hits()
+    h = oracle.Header(); h.term_size = 31; h.canonicalize = 1; h.num_hashes = 1; h.n_docs = n_docs; h.signature_size = S
+    exp = []
+    for qi, (_, s) in enumerate(queries):
+        sc = oracle.scores_rows(row_fn, h, s.encode())
+        for d, v in oracle.select(sc, 120, 0.7):
+            exp.append((qi, d, v))
+    got = [(int(x["query"]), int(x["doc"]), int(x["score"])) for x in hits]
+    assert got == exp and len(exp) >= 17 * 2
+    st = res.stats
+    assert st.n_queries == 50 and st.n_terms == 50 * 120 and st.algorithmic_bytes == 50 * 120 * 83
+
+
+def test_multi_index_search_slots(pm, oracle):
+    rng = np.random.default_rng(10)
+    queries = [(f"m{i}", rand_seq(rng, 150)) for i in range(20)]
+    cases = []
+    for n_docs, S in ((100, 3000), (664, 2000), (4000, 1000)):
+        cases.append(build_case(oracle, rng, n_docs, S, queries, plant=[(i, (i * 13) % n_docs, 0.9) for i in range(0, 20, 2)]))
+    fasta = cases[0][1]
+    ixs = [pm.Index.load_mem(c[0]) for c in cases]
+    q = pm.Queries(fasta)
+    res = pm.search(ixs, q, 0.7, slot_base=40)
+    hits = res.hits()
+    assert set(hits["slot"]) <= {40, 41, 42}
+    for s, (index, _, _) in enumerate(cases):
+        assert pm.format_hits(ixs[s], q, hits, slot=40 + s) == oracle.query_file(index, fasta, 0.7)

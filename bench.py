@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers matched/sec of the MI355X COBS matching stage against a
+661k-shaped synthetic index set, with the HBM roofline of the scan kernel and
+the CPU (oracle "port") baseline timed beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot path (canonicalise + XXH64, row map, row
+gather + bit-sliced count, threshold + compaction, gather of the hit records to
+rank 0 and host ordering) of the query batch over every resident phylogenetic
+batch index.  Workload (BASELINE.json configs[2], SURVEY.md 8d "config 3"): the
+64 661k-shaped batches that fit one GPU (~213 GB of signatures), 100 000
+synthetic 150-bp queries (120 31-mers each), threshold 0.7.  With N > 1 the same
+64 batches are sharded statically over the ranks (strong scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def lanes_per_row(stride):
+    lanes = (min(stride, 1024) + 15) // 16
+    g = 1
+    while g < lanes:
+        g *= 2
+    return g
+
+
+def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
+    """Times oracle/cobs_oracle.c (kind "port": a restatement of the cobs classic
+    search, NOT bioconda cobs 0.2.1) on the host cores: same document counts per
+    batch (same algorithmic bytes per k-mer), rows scaled down to fit host RAM."""
+    from oracle import oracle as O
+    from phylign_amd import workload as W
+    cores = os.cpu_count() or 1
+    total = sum(s.index_bytes for s in shapes)
+    div = max(1, int(np.ceil(total / (sample_gb * 1e9))))
+    small = W.scale_shapes(shapes, div)
+    t0 = time.time()
+    mats = []
+    for s in small:
+        mats.append((s, O.synth_fill(661, s.batch_id, s.signature_size, s.n_docs, cores)))
+    t_gen = time.time() - t0
+    hdrs = []
+    for s, _ in mats:
+        h = O.Header()
+        h.term_size, h.canonicalize, h.num_hashes = 31, 1, 1
+        h.n_docs, h.signature_size, h.row_bytes = s.n_docs, s.signature_size, s.row_bytes
+        hdrs.append(h)
+
+    def run(nq):
+        seqs = fasta_seqs[:nq].tobytes()
+        t = time.time()
+        hits = 0
+        for (s, m), h in zip(mats, hdrs):
+            hits += O.baseline_run(m, s.row_bytes, h, seqs, qlen, nq, threshold, cores)
+        return time.time() - t, hits
+    pilot_q = min(64, len(fasta_seqs))
+    tp, _ = run(pilot_q)
+    nq = int(min(len(fasta_seqs), max(pilot_q, pilot_q * target_s / max(tp, 1e-6))))
+    tt, _ = run(nq)
+    terms = nq * (qlen - 30)
+    alg = terms * sum(s.row_bytes for s in shapes)
+    log(f"[cpu_baseline] gen {t_gen:.1f}s, {nq} queries in {tt:.2f}s on {cores} threads")
+    return {
+        "value": terms / tt, "unit": "k-mers/s", "cores": cores, "kind": "port",
+        "sample": (f"{nq} of the same queries x all {len(shapes)} batch shapes with rows/{div} "
+                   f"({sum(s.index_bytes for s in small) / 1e9:.2f} GB resident in host RAM), "
+                   f"{tt:.1f}s wall, oracle/cobs_oracle.c COBS-restatement (not bioconda cobs 0.2.1)"),
+        "algorithmic_GBps": alg / tt / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config3", choices=["config3", "small", "config2", "full"])
+    ap.add_argument("--queries", type=int, default=100000)
+    ap.add_argument("--qlen", type=int, default=150)
+    ap.add_argument("--threshold", type=float, default=0.7)
+    ap.add_argument("--rows-divisor", type=int, default=1, help="shrink every batch's row count (quick runs)")
+    ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 compact, 2 line-aligned")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-target-s", type=float, default=12.0)
+    ap.add_argument("--cpu-sample-gb", type=float, default=0.85)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    def log(msg):
+        if rank == 0:
+            print(msg, file=sys.stderr, flush=True)
+
+    import torch
+    import torch.distributed as dist
+    from phylign_amd import _lib as pm
+    from phylign_amd import workload as W
+    from phylign_amd.dist import gather_hits
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    pm.init(local_rank)
+    dev = pm.device_info()
+    log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
+
+    shapes = W.select(args.workload)
+    if args.rows_divisor > 1:
+        shapes = W.scale_shapes(shapes, args.rows_divisor)
+    parts = W.assign_batches(shapes, world, capacity_bytes=int(dev["hbm_total"] * 0.85))
+    slot_of = {}     # global slot -> shape position (rank-major numbering)
+    base = 0
+    bases = []
+    for r in range(world):
+        bases.append(base)
+        for i, pos in enumerate(parts[r]):
+            slot_of[base + i] = pos
+        base += len(parts[r])
+    mine = parts[rank]
+
+    # ---- inputs resident in HBM before the timed region -------------------
+    t0 = time.time()
+    fasta, seqs = W.make_queries(args.queries, args.qlen, seed=31)
+    q = pm.Queries(fasta, term_size=31)
+    nq, n_terms = q.count()
+    terms_per_q = args.qlen - 30
+    hashes = q.hash_terms(1, 1)
+    plan, sure_hits = W.plant_plan(hashes, nq, terms_per_q, shapes)
+    del hashes
+    indexes = []
+    for pos in mine:
+        s = shapes[pos]
+        ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, 661, layout=args.layout)
+        if pos in plan:
+            ix.plant(*plan[pos])
+        indexes.append(ix)
+    infos = [ix.info for ix in indexes]
+    resident = sum(i.device_bytes for i in infos)
+    log(f"[bench] rank0: {len(indexes)} batches, {resident / 1e9:.1f} GB of signatures resident, "
+        f"{nq} queries / {n_terms} k-mers, setup {time.time() - t0:.1f}s")
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = {}
+
+    def step():
+        res = pm.search(indexes, q, args.threshold, slot_base=bases[rank])
+        st = res.stats
+        buf = torch.empty((int(st.n_hits), 4), dtype=torch.int32, device="cuda")
+        res.copy_hits_device(buf.data_ptr(), int(st.n_hits))
+        g = gather_hits(buf, dst=0)
+        host = None
+        if rank == 0:
+            host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+            pm.sort_hits(host)
+        last["stats"], last["scan_ms"], last["hits"] = st, res.scan_ms(len(indexes)), host
+        res.free()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    scan_acc = np.zeros(len(indexes))
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        scan_acc += np.array(last["scan_ms"])
+    sync()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_terms / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (per launch, hipEvent-timed) ------
+    scan_ms = scan_acc / args.steps
+    groups = {}
+    for info, ms in zip(infos, scan_ms):
+        key = f"k_scan<G={lanes_per_row(info.stride)},P=7,NH1>"
+        gsum = groups.setdefault(key, [0.0, 0.0, 0])
+        gsum[0] += n_terms * info.num_hashes * info.row_bytes
+        gsum[1] += ms
+        gsum[2] += 1
+    dom = max(groups.items(), key=lambda kv: kv[1][1]) if groups else None
+    roof = None
+    if dom:
+        name, (abytes, ms, launches) = dom
+        achieved = abytes / (ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and tj.get("queries") == args.queries and tj.get("kernel") == name:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": name,
+                "launches_per_step": launches, "avg_launch_ms": ms / launches,
+                "algorithmic_bytes_per_launch": abytes / launches,
+                "all_scan_kernels_GBps": sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9}
+    st = last["stats"]
+    alg_total = sum(shapes[p].row_bytes for p in range(len(shapes))) * n_terms
+
+    out = {
+        "metric": "query k-mers matched/sec vs 661k-shaped COBS index",
+        "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u32 bit-sliced (bitwise + popcount-style integer)", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {len(shapes)} 661k-shaped batches "
+                               f"({sum(s.index_bytes for s in shapes) / 1e9:.1f} GB of signatures, "
+                               f"{sum(s.row_bytes for s in shapes)} row bytes per k-mer), "
+                               f"{nq} synthetic {args.qlen}-bp queries ({terms_per_q} 31-mers each), threshold {args.threshold}",
+                   "batches": len(shapes), "queries": nq, "query_len": args.qlen, "k": 31,
+                   "num_hashes": 1, "threshold": args.threshold, "rows_divisor": args.rows_divisor,
+                   "sharding": f"{world} rank(s), static LPT batch assignment, one gather of hit records"},
+        "hbm_fraction_whole_step": alg_total / (elapsed / args.steps) / (HBM_PEAK_GBPS * 1e9 * world),
+        "hits": int(len(last["hits"])) if last["hits"] is not None else None,
+        "planted_pairs_at_or_above_threshold": sure_hits,
+        "rank0_ms": {"kernels_total": st.ms_total, "hash": st.ms_hash, "scan": st.ms_scan},
+        "roofline": roof,
+    }
+    if rank == 0 and last["hits"] is not None and len(last["hits"]) < sure_hits:
+        sys.exit(f"bench self-check failed: {len(last['hits'])} hits < {sure_hits} planted pairs")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,
+                                           args.cpu_target_s, args.cpu_sample_gb, log)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,8 @@ int  pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint6
 int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                double threshold, uint32_t slot_base, pm_result_t** out);
 int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
+/* hipEvent duration (ms) of the scan launches of each index, ms[0..n) */
+int  pm_result_scan_ms(const pm_result_t* r, double* ms, size_t n);
 /* raw (unordered) records in HBM, e.g. as the send buffer of the RCCL gather */
 int  pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n);
 /* D2D copy of the records into caller-owned device memory (a torch tensor) */
@@ -134,6 +136,9 @@ int  pm_result_copy_hits_device(const pm_result_t* r, void* dst_dptr, uint64_t c
  * library-owned, valid until pm_result_free */
 int  pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n);
 void pm_result_free(pm_result_t* r);
+/* orders records in place by (slot, query, score desc, doc asc): the order of
+ * cobs' result lines; for records gathered from other ranks */
+void pm_hits_sort(pm_hit_t* hits, uint64_t n);
 
 /* ---- text (replaces cobs stdout and, optionally, postprocess_cobs.py) ---- */
 /* Orders `hits` (any order, all slots allowed; only records with slot==slot are

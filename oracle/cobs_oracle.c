@@ -330,6 +330,26 @@ void orc_synth_row(uint64_t seed, uint32_t batch, uint64_t row, uint32_t n_docs,
     }
 }
 
+typedef struct { uint64_t seed; uint32_t batch, n_docs; uint64_t r0, r1, stride; uint8_t* out; } fill_arg;
+static void* fill_worker(void* vp) {
+    fill_arg* a = (fill_arg*)vp;
+    for (uint64_t r = a->r0; r < a->r1; r++) orc_synth_row(a->seed, a->batch, r, a->n_docs, a->out + r * a->stride);
+    return NULL;
+}
+void orc_synth_fill(uint64_t seed, uint32_t batch, uint64_t n_rows, uint32_t n_docs,
+                    uint64_t stride, uint8_t* out, int threads) {
+    if (threads < 1) threads = 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    fill_arg* args = (fill_arg*)calloc((size_t)threads, sizeof(fill_arg));
+    for (int t = 0; t < threads; t++) {
+        args[t] = (fill_arg){seed, batch, n_docs, n_rows * (uint64_t)t / (uint64_t)threads,
+                             n_rows * (uint64_t)(t + 1) / (uint64_t)threads, stride, out};
+        pthread_create(&th[t], NULL, fill_worker, &args[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(args); free(th);
+}
+
 /* ---------------------------------------------------------- CPU baseline  */
 /* COBS-style inner loop (upstream classic_search.cpp compute_counts /
  * aggregate_rows / add_rows): gather the term rows, AND across hash functions,

@@ -76,6 +76,10 @@ uint64_t orc_splitmix64(uint64_t x);
 void orc_synth_row(uint64_t seed, uint32_t batch, uint64_t row, uint32_t n_docs,
                    uint8_t* out);
 
+/* fills n_rows rows (stride bytes apart, zero padded) with `threads` threads */
+void orc_synth_fill(uint64_t seed, uint32_t batch, uint64_t n_rows, uint32_t n_docs,
+                    uint64_t stride, uint8_t* out, int threads);
+
 /* ---- CPU baseline (timed by bench.py): COBS-style expansion-table adds ----
  * Scores `n_queries` equal-length queries against a resident matrix using
  * `threads` threads; returns total hits (to keep the work observable). */

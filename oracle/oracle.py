@@ -56,6 +56,7 @@ def lib():
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_synth_row.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.orc_synth_fill.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
         L.orc_baseline_run.restype = C.c_uint64
         L.orc_baseline_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Header), C.c_char_p, C.c_size_t,
                                        C.c_size_t, C.c_double, C.c_int]
@@ -179,6 +180,15 @@ def synth_matrix(seed: int, batch: int, n_rows: int, n_docs: int):
     m = np.zeros((n_rows, rb), dtype=np.uint8)
     for r in range(n_rows):
         lib().orc_synth_row(seed, batch, r, n_docs, m[r].ctypes.data)
+    return m
+
+
+def synth_fill(seed: int, batch: int, n_rows: int, n_docs: int, threads: int = 1):
+    """whole synthetic matrix [n_rows, ceil(n_docs/8)] built with `threads` threads"""
+    import numpy as np
+    rb = (n_docs + 7) // 8
+    m = np.zeros((n_rows, rb), dtype=np.uint8)
+    lib().orc_synth_fill(seed, batch, n_rows, n_docs, rb, m.ctypes.data, threads)
     return m
 
 

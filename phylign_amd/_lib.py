@@ -65,6 +65,8 @@ SYMBOLS = [
     ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
     ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.POINTER(_P)]),
     ("pm_result_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("pm_result_scan_ms", C.c_int, [_P, C.POINTER(C.c_double), C.c_size_t]),
+    ("pm_hits_sort", None, [_P, C.c_uint64]),
     ("pm_result_hits_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64]),
     ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
@@ -240,6 +242,11 @@ class Result:
         _chk(load().pm_result_stats(self._h, C.byref(s)))
         return s
 
+    def scan_ms(self, n):
+        arr = (C.c_double * n)()
+        _chk(load().pm_result_scan_ms(self._h, arr, n))
+        return list(arr)
+
     def hits_device(self):
         p, n = _P(), C.c_uint64()
         _chk(load().pm_result_hits_device(self._h, C.byref(p), C.byref(n)))
@@ -274,6 +281,13 @@ def search(indexes, queries: Queries, threshold: float, slot_base=0) -> Result:
     h = _P()
     _chk(load().pm_search(arr, len(indexes), queries._h, threshold, slot_base, C.byref(h)))
     return Result(h)
+
+
+def sort_hits(hits):
+    """orders a HIT_DTYPE array in place the way cobs orders result lines"""
+    assert hits.dtype == HIT_DTYPE and hits.flags.c_contiguous
+    load().pm_hits_sort(hits.ctypes.data, hits.size)
+    return hits
 
 
 def format_hits(index: Index, queries: Queries, hits, slot=0, nb_best_hits=-1) -> bytes:

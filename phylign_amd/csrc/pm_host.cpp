@@ -87,6 +87,7 @@ struct pm_result {
     uint64_t n_hits = 0;
     pm_stats_t st{};
     std::vector<pm_hit_t> host;
+    std::vector<double> scan_ms;
     bool host_ready = false;
 };
 
@@ -714,7 +715,11 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
             SCHK(hipEventElapsedTime(&ms, ev0, ev2)); r->st.ms_total = ms;
             SCHK(hipEventElapsedTime(&ms, ev0, ev1)); r->st.ms_hash = ms;
             double scan = 0;
-            for (size_t s = 0; s < n_idx; ++s) { SCHK(hipEventElapsedTime(&ms, sev[2 * s], sev[2 * s + 1])); scan += ms; }
+            r->scan_ms.resize(n_idx);
+            for (size_t s = 0; s < n_idx; ++s) {
+                SCHK(hipEventElapsedTime(&ms, sev[2 * s], sev[2 * s + 1]));
+                r->scan_ms[s] = ms; scan += ms;
+            }
             r->st.ms_scan = scan;
             break;
         }
@@ -734,6 +739,11 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
 extern "C" int pm_result_stats(const pm_result_t* r, pm_stats_t* st) {
     if (!r || !st) return fail(PM_EINVAL, "bad argument");
     *st = r->st;
+    return PM_OK;
+}
+extern "C" int pm_result_scan_ms(const pm_result_t* r, double* ms, size_t n) {
+    if (!r || !ms || n != r->scan_ms.size()) return fail(PM_EINVAL, "bad argument");
+    for (size_t i = 0; i < n; ++i) ms[i] = r->scan_ms[i];
     return PM_OK;
 }
 extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n) {
@@ -758,6 +768,10 @@ static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
     if (a.query != b.query) return a.query < b.query;
     if (a.score != b.score) return a.score > b.score;     // score descending
     return a.doc < b.doc;                                 // then document index ascending
+}
+
+extern "C" void pm_hits_sort(pm_hit_t* hits, uint64_t n) {
+    if (hits && n) std::sort(hits, hits + n, hit_less);
 }
 
 extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {

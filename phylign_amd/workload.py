@@ -1,0 +1,109 @@
+"""661k-shaped synthetic workloads and the static batch->GPU map (8e).
+
+The shape table phylign_amd/data/shapes_661k.tsv is derived from the
+reference's data/661k_batches.txt.xz and data/decompressed_indexes_sizes.txt by
+tools/make_shape_table.py; nothing here reads /root/reference at run time.
+"""
+import os
+from collections import namedtuple
+
+import numpy as np
+
+Shape = namedtuple("Shape", "batch n_docs index_bytes row_bytes signature_size in_small in_config3 batch_id")
+_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "shapes_661k.tsv")
+
+
+def load_shapes(path=_TABLE):
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            b, d, nbytes, rb, s, sm, c3 = line.rstrip("\n").split("\t")
+            out.append(Shape(b, int(d), int(nbytes), int(rb), int(s), bool(int(sm)), bool(int(c3)), len(out)))
+    return out
+
+
+def select(workload, shapes=None):
+    """'config3': the 64 batches of BASELINE.json configs[2] (every 5th of the
+    sorted full list + the 3 batches_small batches, ~213 GB);
+    'small': the 3 batches of data/batches_small.txt; 'full': all 305;
+    'config2': bacillus_anthracis__01 only (BASELINE configs[1])."""
+    shapes = shapes or load_shapes()
+    if workload == "config3":
+        return [s for s in shapes if s.in_config3]
+    if workload == "small":
+        return [s for s in shapes if s.in_small]
+    if workload == "config2":
+        return [s for s in shapes if s.batch == "bacillus_anthracis__01"]
+    if workload == "full":
+        return list(shapes)
+    raise ValueError(workload)
+
+
+def scale_shapes(shapes, rows_divisor):
+    """same document counts (same algorithmic bytes per k-mer), fewer rows"""
+    return [s._replace(signature_size=max(1024, s.signature_size // rows_divisor),
+                       index_bytes=max(1024, s.signature_size // rows_divisor) * s.row_bytes) for s in shapes]
+
+
+def assign_batches(shapes, n_ranks, capacity_bytes=None):
+    """Static batch -> rank map: greedy longest-processing-time on row_bytes (scan
+    work per query k-mer is proportional to the row width), ties broken by index
+    bytes; optional per-rank capacity on the sum of index bytes.  Returns a list
+    of lists of positions into `shapes`, each sorted ascending."""
+    order = sorted(range(len(shapes)), key=lambda i: (-shapes[i].row_bytes, -shapes[i].index_bytes, i))
+    load = [0] * n_ranks
+    used = [0] * n_ranks
+    out = [[] for _ in range(n_ranks)]
+    for i in order:
+        cands = sorted(range(n_ranks), key=lambda r: (load[r], used[r], r))
+        for r in cands:
+            if capacity_bytes is None or used[r] + shapes[i].index_bytes <= capacity_bytes:
+                break
+        else:
+            raise MemoryError(f"batch {shapes[i].batch} does not fit on any rank")
+        out[r].append(i)
+        load[r] += shapes[i].row_bytes
+        used[r] += shapes[i].index_bytes
+    return [sorted(x) for x in out]
+
+
+def make_queries(n, length=150, seed=31):
+    """uniform ACGT queries; returns (fasta bytes, uint8 array [n, length])"""
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, size=(n, length), dtype=np.uint8)
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    hdr = [f">q{i:07d}\n".encode() for i in range(n)]
+    parts = []
+    for i in range(n):
+        parts.append(hdr[i])
+        parts.append(seqs[i].tobytes())
+        parts.append(b"\n")
+    return b"".join(parts), seqs
+
+
+def plant_plan(hashes, n_queries, terms_per_query, shapes, every=20, docs_per_query=8, seed=7):
+    """Planted true positives: every `every`-th query is planted into one batch
+    (round-robin over `shapes`) in `docs_per_query` documents at match fractions
+    cycling through 1.0, 0.9, 0.8, 0.7, 0.65, 0.6.  hashes: uint64 [n_queries*terms]
+    (seed-0 hashes, num_hashes = 1).  Returns {shape position: (rows, docs)} and the
+    number of (query, doc) pairs whose planted fraction alone reaches 0.7."""
+    rng = np.random.default_rng(seed)
+    fr = [1.0, 0.9, 0.8, 0.7, 0.65, 0.6]
+    plan = {}
+    sure = 0
+    h = hashes.reshape(n_queries, terms_per_query)
+    for n, q in enumerate(range(0, n_queries, every)):
+        pos = n % len(shapes)
+        sh = shapes[pos]
+        rows_q = (h[q] % np.uint64(sh.signature_size)).astype(np.uint64)
+        docs = rng.choice(sh.n_docs, size=min(docs_per_query, sh.n_docs), replace=False)
+        for j, d in enumerate(docs):
+            f = fr[j % len(fr)]
+            m = int(np.ceil(f * terms_per_query))
+            r, dd = plan.setdefault(pos, ([], []))
+            r.append(rows_q[:m])
+            dd.append(np.full(m, d, dtype=np.uint32))
+            sure += int(m >= np.ceil(0.7 * terms_per_query))
+    return {p: (np.concatenate(r), np.concatenate(d)) for p, (r, d) in plan.items()}, sure

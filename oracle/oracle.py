@@ -167,6 +167,10 @@ def query_file(index_buf, fasta: bytes, thr: float, num_results: int = 0) -> byt
     return out
 
 
+def splitmix64(x: int) -> int:
+    return lib().orc_splitmix64(x)
+
+
 def synth_row(seed: int, batch: int, row: int, n_docs: int):
     import numpy as np
     out = np.zeros((n_docs + 7) // 8, dtype=np.uint8)

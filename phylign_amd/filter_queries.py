@@ -1,0 +1,120 @@
+"""04_filter consumer of the 03_match files: for every query keep the globally
+best n matches (+ ties with the n-th) across all batch files and emit
+">qname ref1,ref2,...\\nseq".  Behavioural mirror of the reference's
+scripts/filter_queries.py:27-206, pinned by
+tests/golden/filter/*.  Reads .gz or plain text match files.
+"""
+import argparse
+import gzip
+import os
+import sys
+from collections import OrderedDict
+
+
+def _open_text(path):
+    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "rt")
+
+
+def read_queries(path):
+    """FASTA/FASTQ reader: name = first word of the header (reference readfq, :69-103)."""
+    out = OrderedDict()
+    with _open_text(path) as f:
+        lines = [ln.rstrip("\n") for ln in f]
+    i, n = 0, len(lines)
+    while i < n:
+        while i < n and lines[i][:1] not in (">", "@"):
+            i += 1
+        if i >= n:
+            break
+        fastq = lines[i][0] == "@"
+        name = lines[i][1:].partition(" ")[0]
+        i += 1
+        seq = []
+        while i < n and lines[i][:1] not in ("@", "+", ">"):
+            seq.append(lines[i])
+            i += 1
+        seq = "".join(seq)
+        if i < n and lines[i][:1] == "+":       # FASTQ quality block: skip len(seq) characters
+            i += 1
+            got = 0
+            while i < n and got < len(seq):
+                got += len(lines[i])
+                i += 1
+        elif fastq:
+            pass
+        out[name] = seq
+    return out
+
+
+def iter_match_file(path):
+    """yields (qname, [(ref, kmers), ...]) per '*' record of one 03_match file
+    (grammar: reference :46-66: header '*qname[ comment]\\tN', hit '<rid>_<ref>\\t<kmers>')."""
+    qname, hits, seen = None, [], False
+    with _open_text(path) as f:
+        for raw in f:
+            line = raw.strip()
+            if not line:
+                continue
+            if line[0] == "*":
+                if seen:
+                    yield qname, hits
+                head = line[1:].split("\t")
+                qname = head[0].split(" ")[0]
+                int(head[1])                       # must parse, like the reference
+                hits, seen = [], True
+            else:
+                name, kmers = line.split()         # exactly two whitespace-separated fields
+                _rid, ref = name.split("_")        # exactly one underscore
+                hits.append((ref, int(kmers)))
+    if not seen:
+        raise ValueError(f"{path}: no '*' query header in match file")
+    yield qname, hits
+
+
+class TopMatches:
+    """best `keep` (+ties) of one query across batches; order (-kmers, batch, ref)"""
+
+    def __init__(self, keep):
+        self.keep = keep
+        self.floor = 0
+        self.items = []          # (batch, ref, kmers)
+
+    def add(self, batch, hits):
+        for ref, kmers in hits:
+            if kmers >= self.floor:
+                self.items.append((batch, ref, kmers))
+        self.items.sort(key=lambda t: (-t[2], t[0], t[1]))
+        if len(self.items) > self.keep:
+            cut = self.keep
+            self.floor = self.items[cut - 1][2]
+            while cut < len(self.items) and self.items[cut][2] == self.floor:
+                cut += 1
+            del self.items[cut:]
+
+
+def filter_files(query_path, match_paths, keep, out, log=None):
+    seqs = read_queries(query_path)
+    best = OrderedDict((name, TopMatches(keep)) for name in seqs)
+    for path in match_paths:
+        batch = os.path.basename(str(path)).split("____")[0]
+        if log:
+            print(f"Translating matches {path}", file=log)
+        for qname, hits in iter_match_file(path):
+            if qname not in best:
+                raise KeyError(f"{path}: query '{qname}' is not in {query_path}")
+            best[qname].add(batch, hits)
+    for name, top in best.items():
+        out.write(f">{name} {','.join(t[1] for t in top.items)}\n{seqs[name]}\n")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="keep the n best COBS matches per query across batches")
+    ap.add_argument("match_fn", nargs="+")
+    ap.add_argument("-q", dest="query_fn", required=True, help="query file")
+    ap.add_argument("-n", dest="keep", type=int, default=100, help="no. of best hits to keep [100]")
+    a = ap.parse_args(argv)
+    filter_files(a.query_fn, a.match_fn, a.keep, sys.stdout, log=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Multi-GPU path on CPU: static batch sharding and the gather of hit records,
+world_size 2 over gloo (the same code runs over RCCL on the GPUs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from phylign_amd import workload as W
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phylign_amd.dist import gather_hits
+    shapes = W.select("config3")
+    parts = W.assign_batches(shapes, world)
+    bases = np.cumsum([0] + [len(p) for p in parts])
+    # every rank fabricates deterministic "hits" for its own batches
+    rng = np.random.default_rng(100 + rank)
+    n = [37, 0][rank] if world == 2 else 5          # one rank sends nothing: empty send path
+    rec = np.zeros((n, 4), dtype=np.int32)
+    rec[:, 0] = rng.integers(0, 1000, size=n)
+    rec[:, 1] = rng.integers(0, 4000, size=n)
+    rec[:, 2] = rng.integers(84, 121, size=n)
+    rec[:, 3] = bases[rank] + rng.integers(0, len(parts[rank]), size=n)
+    g = gather_hits(torch.from_numpy(rec), dst=0)
+    g2 = gather_hits(torch.from_numpy(rec[::-1].copy()), dst=0)   # a second round on the same group
+    np.save(os.path.join(outdir, f"sent{rank}.npy"), rec)
+    if rank == 0:
+        assert g is not None and g2 is not None
+        np.save(os.path.join(outdir, "gathered.npy"), g.numpy())
+        np.save(os.path.join(outdir, "gathered2.npy"), g2.numpy())
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_hits_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sent = [np.load(tmp_path / f"sent{r}.npy") for r in range(2)]
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape == (37, 4) and np.array_equal(got, np.concatenate(sent))
+    got2 = np.load(tmp_path / "gathered2.npy")
+    assert np.array_equal(got2, np.concatenate([s[::-1] for s in sent]))
+
+
+def test_assign_batches_is_a_balanced_partition():
+    shapes = W.select("config3")
+    assert len(shapes) == 64 and abs(sum(s.index_bytes for s in shapes) / 1e9 - 213.13) < 0.01
+    assert sum(s.row_bytes for s in shapes) == 16285
+    for world in (1, 2, 4, 8):
+        parts = W.assign_batches(shapes, world)
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(64))
+        loads = [sum(shapes[i].row_bytes for i in p) for p in parts]
+        assert max(loads) - min(loads) <= 500          # at most one widest row apart
+        assert max(loads) <= 16285 / world * 1.08
+    with pytest.raises(MemoryError):
+        W.assign_batches(shapes, 2, capacity_bytes=50 * 10**9)
+    full = W.select("full")
+    assert len(full) == 305 and sum(s.row_bytes for s in full) == 82741   # 82 741 B per k-mer
+    parts = W.assign_batches(full, 8, capacity_bytes=int(288e9 * 0.85))
+    assert max(sum(full[i].index_bytes for i in p) for p in parts) < 288e9 * 0.85
+    assert [s.batch for s in W.select("small")] == ["actinobacillus_pleuropneumoniae__01", "aeromonas_salmonicida__01", "bacillus_anthracis__01"]
+
+
+def test_workload_queries_and_plant_plan(oracle):
+    fasta, seqs = W.make_queries(50, 150, seed=31)
+    assert seqs.shape == (50, 150) and fasta.count(b">") == 50
+    assert fasta.split(b"\n")[1] == seqs[0].tobytes()
+    hashes = np.concatenate([oracle.create_hashes(seqs[i].tobytes(), 31, 1, 1) for i in range(50)])
+    shapes = W.scale_shapes(W.select("small"), 1000)
+    plan, sure = W.plant_plan(hashes, 50, 120, shapes, every=10, docs_per_query=6)
+    assert sure == 5 * 4            # fractions 1.0, 0.9, 0.8, 0.7 reach the threshold; 0.65 and 0.6 do not
+    for pos, (rows, docs) in plan.items():
+        assert rows.max() < shapes[pos].signature_size and docs.max() < shapes[pos].n_docs and len(rows) == len(docs)

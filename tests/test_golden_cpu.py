@@ -1,0 +1,246 @@
+"""CPU suite (no GPU): the oracle against golden vectors, the host-side mirrors
+of the reference scripts against fixtures captured from those scripts, and the
+C-ABI library's exported symbols."""
+import glob
+import io
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------ oracle
+def test_oracle_xxh64_known_answers(oracle):
+    n = 0
+    with open(os.path.join(GOLD, "xxh64_kat.tsv")) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            hx, seed, digest = line.rstrip("\n").split("\t")
+            assert oracle.xxh64(bytes.fromhex(hx), int(seed)) == int(digest)
+            n += 1
+    assert n >= 2400 + 71 * 4
+    # SURVEY.md appendix A.3 vectors
+    assert oracle.xxh64(b"ACGTACGTACGTACGTACGTACGTACGTACG", 0) == 3318676550491556742
+    assert oracle.xxh64(b"ACGTACGTACGTACGTACGTACGTACGTACG", 1) == 1345981084757705630
+
+
+def test_oracle_canonicalize(oracle):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rng = np.random.default_rng(0)
+    for k in (1, 2, 5, 30, 31, 32):
+        for _ in range(200):
+            s = "".join("ACGT"[i] for i in rng.integers(0, 4, size=k))
+            rc = "".join(comp[c] for c in reversed(s))
+            assert oracle.canonicalize(s.encode()) == min(s, rc).encode()
+    assert oracle.canonicalize(b"ACGN") is None and oracle.canonicalize(b"acgt") is None
+
+
+def test_oracle_threshold_rule(oracle):
+    # ceil(t * n) in IEEE double: SURVEY.md section 7 hard part (a)
+    assert oracle.threshold(0.7, 120) == 84
+    assert oracle.threshold(0.7, 121) == 85
+    assert oracle.threshold(0.7, 1) == 1
+    assert oracle.threshold(0.5, 3) == 2
+    assert oracle.threshold(1.0, 120) == 120
+    assert oracle.threshold(0.0, 120) == 0
+    import math
+    for n in range(1, 400):
+        for t in (0.1, 0.35, 0.7, 0.8, 0.95):
+            assert oracle.threshold(t, n) == math.ceil(t * n)
+
+
+def test_oracle_header_roundtrip_and_both_layouts(oracle):
+    names = ["abc_S1", "x_S2", "yy_S3", "zzzzzzzz_S4", "q_S5"]
+    m = np.arange(7 * 1, dtype=np.uint8).reshape(7, 1)
+    idx = oracle.make_index(31, 1, 7, 2, names, m)
+    h = oracle.header_parse(idx)
+    assert (h.term_size, h.canonicalize, h.signature_size, h.num_hashes, h.n_docs, h.row_bytes, h.layout) == (31, 1, 7, 2, 5, 1, 0)
+    assert bytes(idx[h.data_off:]) == m.tobytes()
+    assert bytes(idx[:18]) == b"COBS:CLASSIC_INDEX"
+    # SURVEY appendix A.1 field order (sig, hashes, n_docs): re-pack and parse again
+    b = bytearray(idx)
+    o = 18 + 4 + 4 + 1
+    n_docs, sig, nh = b[o:o + 4], b[o + 4:o + 12], b[o + 12:o + 20]
+    b[o:o + 20] = sig + nh + n_docs
+    h2 = oracle.header_parse(bytes(b))
+    assert (h2.signature_size, h2.num_hashes, h2.n_docs, h2.layout) == (7, 2, 5, 1)
+    with pytest.raises(ValueError):
+        oracle.header_parse(b"COBS:COMPACT_INDEX" + bytes(64))
+
+
+def test_oracle_scores_bruteforce_python(oracle):
+    """C restatement vs a pure-Python loop on a tiny case (independent of the C scoring code)."""
+    rng = np.random.default_rng(3)
+    n_docs, S, k, nh = 19, 53, 5, 2
+    bits = rng.random((S, 24)) < 0.4
+    bits[:, n_docs:] = False
+    matrix = np.packbits(bits, axis=1, bitorder="little")
+    idx = oracle.make_index(k, 1, S, nh, [f"p_d{i}" for i in range(n_docs)], matrix)
+    seq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=40))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    exp = [0] * n_docs
+    for i in range(len(seq) - k + 1):
+        km = seq[i:i + k]
+        can = min(km, "".join(comp[c] for c in reversed(km))).encode()
+        rows = [oracle.xxh64(can, j) % S for j in range(nh)]
+        for d in range(n_docs):
+            exp[d] += all(bits[r, d] for r in rows)
+    assert list(oracle.scores(idx, seq.encode())) == exp
+    sel = oracle.select(np.array(exp, dtype=np.uint32), len(seq) - k + 1, 0.3)
+    assert sel == sorted([(d, s) for d, s in enumerate(exp) if s >= oracle.threshold(0.3, len(seq) - k + 1)],
+                         key=lambda t: (-t[1], t[0]))
+    text = oracle.query_file(idx, f">q1 c\n{seq}\n".encode(), 0.3).decode().split("\n")
+    assert text[0] == f"*q1 c\t{len(sel)}"
+    assert text[1:-1] == [f"p_d{d}\t{s}" for d, s in sel]
+
+
+def test_oracle_output_feeds_reference_grammar(oracle):
+    """the oracle's text obeys the grammar the reference's consumers parse
+    (scripts/postprocess_cobs.py:23-39, scripts/filter_queries.py:51-65)."""
+    from helpers import build_case, rand_seq
+    rng = np.random.default_rng(4)
+    qs = [(f"r{i} comment", rand_seq(rng, 100)) for i in range(6)]
+    idx, fasta, _ = build_case(oracle, rng, 50, 400, qs, plant=[(i, i, 1.0) for i in range(6)])
+    out = oracle.query_file(idx, fasta, 0.7).decode()
+    n_left = 0
+    for line in out.splitlines():
+        if line.startswith("*"):
+            assert n_left == 0
+            n_left = int(line[1:].split("\t")[1])
+        else:
+            name, score = line.split()
+            assert len(name.split("_")) == 2 and int(score) >= 49
+            n_left -= 1
+    assert n_left == 0
+
+
+def test_synth_spec_is_stable(oracle):
+    """pins the build's synthetic-matrix generator (both the oracle copy and the device kernel follow it)"""
+    assert oracle.splitmix64(0) == 0xE220A8397B1DCDAF
+    r = oracle.synth_row(661, 3, 12345, 664)
+    assert r.shape == (83,) and np.array_equal(r[:2], oracle.synth_row(661, 3, 12345, 16))
+    assert oracle.synth_row(661, 3, 5, 13)[1] < 32      # bits >= n_docs are zero
+    m = oracle.synth_fill(661, 9, 300, 1000, 3)
+    assert np.array_equal(m[299], oracle.synth_row(661, 9, 299, 1000))
+    dens = np.unpackbits(m, axis=1, bitorder="little")[:, :1000].mean()
+    assert 0.23 < dens < 0.27
+
+
+# ------------------------------------------------- postprocess mirror (a8)
+def _post_cases():
+    return sorted(glob.glob(os.path.join(GOLD, "postprocess", "*.in")))
+
+
+@pytest.mark.parametrize("inp", _post_cases(), ids=lambda p: os.path.basename(p)[:-3])
+def test_postprocess_matches_reference_fixtures(inp):
+    from phylign_amd import postprocess as P
+    text = open(inp).read()
+    base = inp[:-3]
+    seen = 0
+    for n in (0, 1, 2, 3, 100):
+        out = io.StringIO()
+        ok = True
+        try:
+            P.filter_stream(io.StringIO(text), n, out)
+        except (ValueError, P.PostprocessError):
+            ok = False
+        if os.path.exists(f"{base}.n{n}.out"):
+            assert ok and out.getvalue() == open(f"{base}.n{n}.out").read()
+        else:
+            assert not ok and out.getvalue() == open(f"{base}.n{n}.fail").read()
+        seen += 1
+    assert seen == 5
+
+
+def test_postprocess_script_exit_codes():
+    script = os.path.join(ROOT, "scripts", "postprocess_cobs.py")
+    text = open(os.path.join(GOLD, "postprocess", "survey_a4.in"), "rb").read()
+    r = subprocess.run([sys.executable, script, "-n", "2"], input=text, capture_output=True)
+    assert r.returncode == 0 and r.stdout == open(os.path.join(GOLD, "postprocess", "survey_a4.n2.out"), "rb").read()
+    bad = open(os.path.join(GOLD, "postprocess", "headerless.in"), "rb").read()
+    r = subprocess.run([sys.executable, script, "-n", "2"], input=bad, capture_output=True)
+    assert r.returncode != 0
+
+
+# ---------------------------------------------------- 04_filter mirror (f1)
+@pytest.mark.parametrize("n", [1, 2, 5, 100])
+def test_filter_queries_matches_reference_fixture(n):
+    from phylign_amd import filter_queries as F
+    d = os.path.join(GOLD, "filter")
+    files = [os.path.join(d, f"{b}____q.gz") for b in ("aaa_bbb__01", "ccc_ddd__01", "ccc_ddd__02")]
+    out = io.StringIO()
+    F.filter_files(os.path.join(d, "queries.fa"), files, n, out)
+    assert out.getvalue() == open(os.path.join(d, f"expected.n{n}.fa")).read()
+
+
+# ----------------------------------------------------- sizing mirror (a10)
+def test_sizing_helpers_match_snakefile_vectors(tmp_path):
+    from phylign_amd import sizing as Z
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(GOLD, "sizing.tsv")) if not l.startswith("#")]
+    table = tmp_path / "sizes.txt"
+    seen = {}
+    for r in rows:
+        seen[r[0]] = (r[5], int(r[6]))
+    with open(table, "w") as f:
+        f.write("cobs/zzz_other__01.cobs_classic.xz  123  456\n")
+        for b, (sz, xz_mb) in seen.items():
+            # xz RAM bytes chosen so that int(bytes/MiB)+1 == the recorded MB
+            f.write(f"cobs/{b}.cobs_classic.xz  {sz}  {(xz_mb - 1) * 1024 * 1024 + 7}\n")
+    for b, streaming, ct, cores, ram, size, xz_mb, ram_mb, threads in rows:
+        assert Z.index_metadata(b, table)[0] == int(size)
+        assert Z.xz_ram_mb(b, table) == int(xz_mb)
+        assert Z.batch_ram_mb(b, table, False, bool(int(streaming))) == int(ram_mb)
+        assert Z.cobs_threads(b, table, ct, int(cores), int(ram), bool(int(streaming))) == int(threads)
+    assert len(rows) == 216
+
+
+# ------------------------------------------------------------ C ABI surface
+def test_c_abi_exports_every_declared_symbol():
+    from phylign_amd import _lib
+    L = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "phylign_match.h")).read()
+    declared = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from phylign_amd import _lib
+    with pytest.raises(_lib.PMError) as e:
+        _lib.init(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(_lib.PMError) as e:
+        _lib.Queries(b">q\nACGT\n", term_size=3)
+    assert e.value.code == -2
+    # the one host-only rule of the path is callable without a device and equals the oracle's
+    assert _lib.threshold_terms(0.7, 121) == 85
+
+
+def test_threshold_rule_product_equals_oracle(oracle):
+    from phylign_amd import _lib
+    _lib.load()
+    for n in list(range(1, 300)) + [1000, 65535, 70000]:
+        for t in (0.0, 0.1, 0.5, 0.7, 0.75, 0.9, 1.0):
+            assert _lib.threshold_terms(t, n) == oracle.threshold(t, n)
+
+
+def test_product_never_imports_oracle():
+    """the product path must not route through the oracle (or any CPU fallback)"""
+    for path in glob.glob(os.path.join(ROOT, "phylign_amd", "**", "*"), recursive=True) + \
+            glob.glob(os.path.join(ROOT, "scripts", "*")):
+        if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
+            src = open(path).read()
+            assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or path.endswith("build.py"), path

@@ -1,0 +1,117 @@
+"""Drop-in boundary on the GPU: the reference's command lines
+(scripts/run_cobs_streaming.sh:13-29, Snakefile:463-469) against the oracle."""
+import gzip
+import io
+import lzma
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import build_case, rand_seq
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(oracle, seed=21, n_docs=664, S=30000, nq=24):
+    rng = np.random.default_rng(seed)
+    queries = [(f"{i}A some comment" if i % 2 else f"{i}B", rand_seq(rng, 150)) for i in range(nq)]
+    plant = []
+    for qi in range(nq):
+        for j, frac in enumerate((1.0, 0.9, 0.9, 0.9, 0.8, 0.75, 0.75, 0.7, 0.6)):
+            plant.append((qi, (qi * 17 + j * 5) % n_docs, frac))
+    return build_case(oracle, rng, n_docs, S, queries, plant=plant)
+
+
+def test_run_cobs_streaming_script(pm, oracle, tmp_path):
+    index, fasta, _ = _case(oracle)
+    xz = tmp_path / "bacillus_anthracis__01.cobs_classic.xz"
+    xz.write_bytes(lzma.compress(bytes(index), preset=1))
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(fasta)
+    script = os.path.join(ROOT, "scripts", "run_cobs_streaming.sh")
+    r = subprocess.run([script, "0.7", "4", str(xz), str(len(index)), str(fa)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    exp = oracle.query_file(index, fasta, 0.7)
+    assert r.stdout == exp
+    # wrong argument count -> usage + exit 1 (scripts/run_cobs_streaming.sh:13-16)
+    r2 = subprocess.run([script, "0.7", "4"], capture_output=True)
+    assert r2.returncode == 1 and b"usage" in r2.stderr
+    # truncated index stream -> non-zero exit, nothing that looks like a complete result
+    bad = tmp_path / "bad.cobs_classic.xz"
+    bad.write_bytes(lzma.compress(bytes(index[: len(index) // 2]), preset=1))
+    r3 = subprocess.run([script, "0.7", "4", str(bad), str(len(index)), str(fa)], capture_output=True)
+    assert r3.returncode != 0 and r3.stdout == b""
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 100])
+def test_rule_pipeline_and_fused_postprocess(pm, oracle, tmp_path, n):
+    """`run_cobs_streaming.sh ... | postprocess_cobs.py -n N | gzip --fast` (Snakefile:466-469)"""
+    from phylign_amd import postprocess as P
+    index, fasta, _ = _case(oracle, seed=22)
+    xz = tmp_path / "b__01.cobs_classic.xz"
+    xz.write_bytes(lzma.compress(bytes(index), preset=1))
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(fasta)
+    out = tmp_path / "b__01____q.gz"
+    sdir = os.path.join(ROOT, "scripts")
+    cmd = (f"set -euo pipefail; {sdir}/run_cobs_streaming.sh 0.7 2 '{xz}' {len(index)} '{fa}' "
+           f"| {sdir}/postprocess_cobs.py -n {n} | gzip --fast > '{out}'")
+    r = subprocess.run(["bash", "-c", cmd], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    exp = P.filter_text(oracle.query_file(index, fasta, 0.7).decode(), n)
+    assert gzip.open(out, "rt").read() == exp
+    # fused in-library post-filter gives the same bytes
+    ix = pm.Index.load_mem(index)
+    assert pm.query_text(ix, fasta, 0.7, nb_best_hits=n).decode() == exp
+    env = dict(os.environ, PHYLIGN_NB_BEST_HITS=str(n))
+    r = subprocess.run([f"{sdir}/run_cobs_streaming.sh", "0.7", "2", str(xz), str(len(index)), str(fa)],
+                       capture_output=True, env=env)
+    assert r.returncode == 0 and r.stdout.decode() == exp
+
+
+def test_cobs_query_cli_plain_file(pm, oracle, tmp_path):
+    """non-streaming form: `cobs query --load-complete -t T -T n -i index -f q.fa` (Snakefile:419-424)"""
+    index, fasta, _ = _case(oracle, seed=23, n_docs=195, S=9000)
+    p = tmp_path / "i.cobs_classic"
+    p.write_bytes(bytes(index))
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(fasta)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.cobs_query", "query", "--load-complete", "-t", "0.7", "-T", "8",
+                        "-i", str(p), "-f", str(fa)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == oracle.query_file(index, fasta, 0.7)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.cobs_query", "query", "-t", "0.7", "-i", str(tmp_path / "missing"),
+                        "-f", str(fa)], capture_output=True, env=env)
+    assert r.returncode == 1 and b"cannot open index" in r.stderr
+
+
+def test_match_to_filter_dropin(pm, oracle, tmp_path):
+    """03_match files of three batches feed the 04_filter consumer (Snakefile:490-520)."""
+    from phylign_amd import filter_queries as F
+    from phylign_amd import postprocess as P
+    rng = np.random.default_rng(31)
+    queries = [(f"r{i}", rand_seq(rng, 120)) for i in range(12)]
+    files, exp_files = [], []
+    for b, (n_docs, S) in enumerate(((195, 5000), (176, 7000), (664, 6000))):
+        plant = [(qi, (qi * 7 + j) % n_docs, fr) for qi in range(12) for j, fr in enumerate((1.0, 0.9, 0.8, 0.8, 0.7))]
+        index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant)
+        ix = pm.Index.load_mem(index)
+        got = pm.query_text(ix, fasta, 0.7, nb_best_hits=3)
+        exp = P.filter_text(oracle.query_file(index, fasta, 0.7).decode(), 3)
+        assert got.decode() == exp
+        fn = tmp_path / f"batch_{b}__01____q.gz"
+        with gzip.open(fn, "wb") as f:
+            f.write(got)
+        files.append(str(fn))
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(fasta)
+    out = io.StringIO()
+    F.filter_files(str(fa), files, 3, out)
+    recs = out.getvalue().strip().split("\n")
+    assert len(recs) == 24 and recs[0].startswith(">r0 ")
+    assert all(len(recs[i].split(" ")[1].split(",")) >= 3 for i in range(0, 24, 2))

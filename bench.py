@@ -29,14 +29,6 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def lanes_per_row(stride):
-    lanes = (min(stride, 1024) + 15) // 16
-    g = 1
-    while g < lanes:
-        g *= 2
-    return g
-
-
 def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
     """Times oracle/cobs_oracle.c (kind "port": a restatement of the cobs classic
     search, NOT bioconda cobs 0.2.1) on the host cores: same document counts per
@@ -66,10 +58,13 @@ def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
         for (s, m), h in zip(mats, hdrs):
             hits += O.baseline_run(m, s.row_bytes, h, seqs, qlen, nq, threshold, cores)
         return time.time() - t, hits
-    pilot_q = min(64, len(fasta_seqs))
-    tp, _ = run(pilot_q)
-    nq = int(min(len(fasta_seqs), max(pilot_q, pilot_q * target_s / max(tp, 1e-6))))
+    nq = min(256, len(fasta_seqs))
     tt, _ = run(nq)
+    for _ in range(4):                  # grow the sample until it costs about target_s of CPU time
+        if tt >= 0.5 * target_s or nq >= len(fasta_seqs):
+            break
+        nq = int(min(len(fasta_seqs), max(nq * 2, nq * target_s / max(tt, 1e-6))))
+        tt, _ = run(nq)
     terms = nq * (qlen - 30)
     alg = terms * sum(s.row_bytes for s in shapes)
     log(f"[cpu_baseline] gen {t_gen:.1f}s, {nq} queries in {tt:.2f}s on {cores} threads")
@@ -96,6 +91,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--cpu-sample-gb", type=float, default=0.85)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single process: hold only the shard rank --emulate-rank would get in an N-way split "
+                         "(estimates the per-rank step time of a strong-scaling run; not a reported number)")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,11 +117,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1: functional check of the N>1 code path
+    # with several ranks on ONE GPU (RCCL refuses duplicate devices); never a reported number
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
     dev = pm.device_info()
     log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
@@ -130,16 +137,18 @@ def main():
     shapes = W.select(args.workload)
     if args.rows_divisor > 1:
         shapes = W.scale_shapes(shapes, args.rows_divisor)
-    parts = W.assign_batches(shapes, world, capacity_bytes=int(dev["hbm_total"] * 0.85))
+    nparts = args.emulate_world if (args.emulate_world and world == 1) else world
+    parts = W.assign_batches(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))
     slot_of = {}     # global slot -> shape position (rank-major numbering)
     base = 0
     bases = []
-    for r in range(world):
+    for r in range(nparts):
         bases.append(base)
         for i, pos in enumerate(parts[r]):
             slot_of[base + i] = pos
         base += len(parts[r])
-    mine = parts[rank]
+    part_id = args.emulate_rank if nparts != world else rank
+    mine = parts[part_id]
 
     # ---- inputs resident in HBM before the timed region -------------------
     t0 = time.time()
@@ -170,49 +179,51 @@ def main():
 
     last = {}
 
+    phase = {"search": 0.0, "gather": 0.0, "host": 0.0}
+
     def step():
-        res = pm.search(indexes, q, args.threshold, slot_base=bases[rank])
+        t_a = time.perf_counter()
+        res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id])
         st = res.stats
         buf = torch.empty((int(st.n_hits), 4), dtype=torch.int32, device="cuda")
+        t_b = time.perf_counter()
         res.copy_hits_device(buf.data_ptr(), int(st.n_hits))
-        g = gather_hits(buf, dst=0)
+        g = gather_hits(buf if backend == "nccl" else buf.cpu(), dst=0)
+        t_c = time.perf_counter()
         host = None
         if rank == 0:
             host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
             pm.sort_hits(host)
-        last["stats"], last["scan_ms"], last["hits"] = st, res.scan_ms(len(indexes)), host
+        t_d = time.perf_counter()
+        phase["search"] += t_b - t_a; phase["gather"] += t_c - t_b; phase["host"] += t_d - t_c
+        last["stats"], last["launches"], last["hits"] = st, res.launches(), host
         res.free()
 
     for _ in range(args.warmup):
         step()
     sync()
-    scan_acc = np.zeros(len(indexes))
+    phase.update(search=0.0, gather=0.0, host=0.0)
+    groups = {}      # kernel instantiation -> [algorithmic bytes, ms, launches] summed over the timed steps
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        scan_acc += np.array(last["scan_ms"])
+        for L in last["launches"]:
+            g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])
+            g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
     sync()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n_terms / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (per launch, hipEvent-timed) ------
-    scan_ms = scan_acc / args.steps
-    groups = {}
-    for info, ms in zip(infos, scan_ms):
-        key = f"k_scan<G={lanes_per_row(info.stride)},P=7,NH1>"
-        gsum = groups.setdefault(key, [0.0, 0.0, 0])
-        gsum[0] += n_terms * info.num_hashes * info.row_bytes
-        gsum[1] += ms
-        gsum[2] += 1
     dom = max(groups.items(), key=lambda kv: kv[1][1]) if groups else None
     roof = None
     if dom:
-        name, (abytes, ms, launches) = dom
+        name, (abytes, ms, launches, nb) = dom
         achieved = abytes / (ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -225,7 +236,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": name,
-                "launches_per_step": launches, "avg_launch_ms": ms / launches,
+                "launches_per_step": launches / args.steps, "batches_per_launch": nb, "avg_launch_ms": ms / launches,
                 "algorithmic_bytes_per_launch": abytes / launches,
                 "all_scan_kernels_GBps": sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9}
     st = last["stats"]
@@ -246,10 +257,17 @@ def main():
         "hbm_fraction_whole_step": alg_total / (elapsed / args.steps) / (HBM_PEAK_GBPS * 1e9 * world),
         "hits": int(len(last["hits"])) if last["hits"] is not None else None,
         "planted_pairs_at_or_above_threshold": sure_hits,
-        "rank0_ms": {"kernels_total": st.ms_total, "hash": st.ms_hash, "scan": st.ms_scan},
+        "rank0_ms": {"kernels_total": st.ms_total, "hash": st.ms_hash, "scan": st.ms_scan,
+                     "host_search_call": phase["search"] / args.steps * 1e3,
+                     "host_hit_gather": phase["gather"] / args.steps * 1e3,
+                     "host_d2h_and_order": phase["host"] / args.steps * 1e3},
+        "scan_launches": {k: {"launches_per_step": v[2] / args.steps, "batches": v[3], "avg_ms": v[1] / v[2],
+                              "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in groups.items()},
         "roofline": roof,
     }
-    if rank == 0 and last["hits"] is not None and len(last["hits"]) < sure_hits:
+    if args.emulate_world:
+        out["emulated_shard"] = f"rank {part_id} of {nparts}"
+    if rank == 0 and not args.emulate_world and last["hits"] is not None and len(last["hits"]) < sure_hits:
         sys.exit(f"bench self-check failed: {len(last['hits'])} hits < {sure_hits} planted pairs")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,

@@ -67,12 +67,22 @@ typedef struct {
     uint64_t n_queries, n_terms;     /* FASTA records / k-mers in the query set */
     uint64_t n_hits;                 /* hits over all slots */
     uint64_t algorithmic_bytes;      /* sum_slots n_terms * num_hashes * row_bytes */
-    double   ms_total;               /* hipEvent time: hash + row-map + scan kernels */
+    double   ms_total;               /* hipEvent time: hash + scan kernels */
     double   ms_hash;                /* canonicalise + XXH64 kernel */
     double   ms_scan;                /* sum of scan-kernel launch durations */
     uint32_t n_scan_launches;
     uint32_t reserved;
 } pm_stats_t;
+
+typedef struct {
+    uint32_t lanes_per_row;      /* template parameter G of k_scan */
+    uint32_t planes;             /* template parameter P of k_scan */
+    uint32_t num_hashes;
+    uint32_t n_batches;          /* batch indexes covered by the launch */
+    uint64_t n_queries;
+    uint64_t algorithmic_bytes;  /* sum over its batches and k-mers of num_hashes * row_bytes */
+    double   ms;                 /* hipEvent duration on the launch stream */
+} pm_launch_t;
 
 /* ---- runtime ---------------------------------------------------------- */
 int  pm_init(int device);                 /* bind this process to GPU `device` */
@@ -126,8 +136,10 @@ int  pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint6
 int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                double threshold, uint32_t slot_base, pm_result_t** out);
 int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
-/* hipEvent duration (ms) of the scan launches of each index, ms[0..n) */
-int  pm_result_scan_ms(const pm_result_t* r, double* ms, size_t n);
+/* the scan-kernel launches of the search (one per row-width class x counter-width
+ * class, each covering all batches of the class) with their hipEvent durations;
+ * writes min(cap, *n) entries, *n = number of launches */
+int  pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size_t* n);
 /* raw (unordered) records in HBM, e.g. as the send buffer of the RCCL gather */
 int  pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n);
 /* D2D copy of the records into caller-owned device memory (a torch tensor) */

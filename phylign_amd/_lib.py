@@ -37,6 +37,12 @@ class Stats(C.Structure):
                 ("ms_scan", C.c_double), ("n_scan_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class Launch(C.Structure):
+    _fields_ = [("lanes_per_row", C.c_uint32), ("planes", C.c_uint32), ("num_hashes", C.c_uint32),
+                ("n_batches", C.c_uint32), ("n_queries", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("ms", C.c_double)]
+
+
 HIT_DTYPE = np.dtype([("query", "<u4"), ("doc", "<u4"), ("score", "<u4"), ("slot", "<u4")])
 
 # every symbol include/phylign_match.h declares: (name, restype, argtypes)
@@ -65,7 +71,7 @@ SYMBOLS = [
     ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
     ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.POINTER(_P)]),
     ("pm_result_stats", C.c_int, [_P, C.POINTER(Stats)]),
-    ("pm_result_scan_ms", C.c_int, [_P, C.POINTER(C.c_double), C.c_size_t]),
+    ("pm_result_launches", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pm_hits_sort", None, [_P, C.c_uint64]),
     ("pm_result_hits_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64]),
@@ -242,10 +248,16 @@ class Result:
         _chk(load().pm_result_stats(self._h, C.byref(s)))
         return s
 
-    def scan_ms(self, n):
-        arr = (C.c_double * n)()
-        _chk(load().pm_result_scan_ms(self._h, arr, n))
-        return list(arr)
+    def launches(self):
+        """scan-kernel launches of this search: dicts with the kernel's template
+        parameters, batches covered, algorithmic bytes and hipEvent ms"""
+        n = C.c_size_t()
+        _chk(load().pm_result_launches(self._h, None, 0, C.byref(n)))
+        arr = (Launch * max(n.value, 1))()
+        _chk(load().pm_result_launches(self._h, arr, n.value, C.byref(n)))
+        return [{"kernel": f"k_scan<G={a.lanes_per_row},P={a.planes},{'NH1' if a.num_hashes == 1 else 'NHn'}>",
+                 "n_batches": a.n_batches, "n_queries": a.n_queries,
+                 "algorithmic_bytes": a.algorithmic_bytes, "ms": a.ms} for a in arr[: n.value]]
 
     def hits_device(self):
         p, n = _P(), C.c_uint64()

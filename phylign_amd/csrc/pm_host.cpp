@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <map>
 #include <string>
+#include <tuple>
 #include <unistd.h>
 #include <vector>
 
@@ -40,11 +42,18 @@ static int fail(int code, const char* fmt, ...) {
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);             \
     } while (0)
 
+struct HitBuf { uint4* p; uint64_t cap; };
 struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;
+    // persistent search workspace (grow-only; nothing is allocated per search
+    // once warm): hit counter, batch descriptors, timing events, hit buffers
+    unsigned long long* d_cnt = nullptr;
+    BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr; size_t desc_cap = 0;
+    std::vector<hipEvent_t> events;
+    std::vector<HitBuf> free_hits;
 };
 static Ctx g_ctx;
 #define NEED_DEV()                                                                         \
@@ -77,8 +86,11 @@ struct pm_queries {
     QDesc* d_qd = nullptr;
     uint32_t* d_blkq = nullptr;
     uint32_t* d_qmap = nullptr;
-    uint64_t* d_hashes = nullptr;
-    int hash_canon = -1; uint32_t hash_nh = 0;
+    uint32_t* d_thr = nullptr; double thr_for = -1.0;      // per-query minimum score, cached per threshold
+    // hash buffers per (canonicalize, num_hashes); the kernel re-runs once per pm_search
+    struct HashBuf { int canon; uint32_t nh; uint64_t* d; uint64_t epoch; };
+    std::vector<HashBuf> hashes;
+    uint64_t epoch = 0;
 };
 
 struct pm_result {
@@ -87,11 +99,13 @@ struct pm_result {
     uint64_t n_hits = 0;
     pm_stats_t st{};
     std::vector<pm_hit_t> host;
-    std::vector<double> scan_ms;
+    std::vector<pm_launch_t> launches;
     bool host_ready = false;
 };
 
 static const int kPlaneClass[4] = {7, 10, 16, 24};
+// experiment switch for kernel variants (PM_SCAN_FLAGS env, read at pm_init)
+static uint32_t g_scan_flags = 0;
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
@@ -114,6 +128,7 @@ extern "C" int pm_init(int device) {
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
     g_ctx.device = device;
     g_ctx.ready = true;
+    if (const char* f = getenv("PM_SCAN_FLAGS")) g_scan_flags = (uint32_t)strtoul(f, nullptr, 0);
     return PM_OK;
 }
 
@@ -121,6 +136,11 @@ extern "C" void pm_shutdown(void) {
     if (!g_ctx.ready) return;
     hipStreamDestroy(g_ctx.stream);
     hipStreamDestroy(g_ctx.copy_stream);
+    if (g_ctx.d_cnt) hipFree(g_ctx.d_cnt);
+    if (g_ctx.d_desc) hipFree(g_ctx.d_desc);
+    if (g_ctx.h_desc) hipHostFree(g_ctx.h_desc);
+    for (auto e : g_ctx.events) hipEventDestroy(e);
+    for (auto& b : g_ctx.free_hits) hipFree(b.p);
     g_ctx = Ctx();
 }
 
@@ -556,7 +576,8 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
     };
     hipError_t e;
     if (nq) {
-        if ((e = hipMalloc((void**)&q->d_seq, std::max<size_t>(seqs.size(), 16))) != hipSuccess) return bail(e, "hipMalloc seq");
+        if ((e = hipMalloc((void**)&q->d_seq, seqs.size() + 64)) != hipSuccess) return bail(e, "hipMalloc seq");
+        if ((e = hipMemset(q->d_seq, 0, seqs.size() + 64)) != hipSuccess) return bail(e, "memset seq");
         if ((e = hipMalloc((void**)&q->d_qd, nq * sizeof(QDesc))) != hipSuccess) return bail(e, "hipMalloc qd");
         if ((e = hipMalloc((void**)&q->d_blkq, std::max<size_t>(blkq.size(), 1) * 4)) != hipSuccess) return bail(e, "hipMalloc blkq");
         if ((e = hipMalloc((void**)&q->d_qmap, nq * 4)) != hipSuccess) return bail(e, "hipMalloc qmap");
@@ -586,30 +607,40 @@ extern "C" void pm_queries_free(pm_queries_t* q) {
     if (q->d_qd) hipFree(q->d_qd);
     if (q->d_blkq) hipFree(q->d_blkq);
     if (q->d_qmap) hipFree(q->d_qmap);
-    if (q->d_hashes) hipFree(q->d_hashes);
+    if (q->d_thr) hipFree(q->d_thr);
+    for (auto& h : q->hashes) if (h.d) hipFree(h.d);
     delete q;
 }
 
-// hashes for (canonicalize, num_hashes), cached on the query set
-static int ensure_hashes(pm_queries* q, int canon, uint32_t nh) {
-    if (q->d_hashes && q->hash_canon == canon && q->hash_nh == nh) return PM_OK;
-    if (q->d_hashes) { hipFree(q->d_hashes); q->d_hashes = nullptr; }
-    if (q->n_slots == 0) { q->hash_canon = canon; q->hash_nh = nh; return PM_OK; }
-    HIPCHK(hipMalloc((void**)&q->d_hashes, q->n_slots * nh * 8));
-    HIPCHK(launch_hash_terms(q->d_seq, q->d_qd, q->d_blkq, q->n_slots, q->k, canon, nh, q->d_hashes, g_ctx.stream));
-    q->hash_canon = canon; q->hash_nh = nh;
+// Device hashes for (canonicalize, num_hashes).  The buffer is kept on the query
+// set; the kernel runs once per epoch (pm_search bumps the epoch: one job =
+// hash + scan, nothing is carried over between searches).
+static int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out) {
+    pm_queries::HashBuf* hb = nullptr;
+    for (auto& h : q->hashes) if (h.canon == canon && h.nh == nh) hb = &h;
+    if (!hb) {
+        q->hashes.push_back({canon, nh, nullptr, ~0ull});
+        hb = &q->hashes.back();
+        if (q->n_slots) HIPCHK(hipMalloc((void**)&hb->d, q->n_slots * nh * 8));
+    }
+    if (hb->epoch != q->epoch) {
+        HIPCHK(launch_hash_terms(q->d_seq, q->d_qd, q->d_blkq, q->n_slots, q->k, canon, nh, hb->d, g_ctx.stream));
+        hb->epoch = q->epoch;
+    }
+    *out = hb->d;
     return PM_OK;
 }
 
 extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out) {
     NEED_DEV();
     if (!q || !out || num_hashes == 0) return fail(PM_EINVAL, "bad argument");
-    q->hash_canon = -1;   // force a fresh kernel run
-    int rc = ensure_hashes(q, canonicalize ? 1 : 0, num_hashes);
+    q->epoch++;           // force a fresh kernel run
+    uint64_t* d_h = nullptr;
+    int rc = ensure_hashes(q, canonicalize ? 1 : 0, num_hashes, &d_h);
     if (rc) return rc;
     std::vector<uint64_t> padded((size_t)(q->n_slots * num_hashes));
     if (!padded.empty())
-        HIPCHK(hipMemcpyAsync(padded.data(), q->d_hashes, padded.size() * 8, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIPCHK(hipMemcpyAsync(padded.data(), d_h, padded.size() * 8, hipMemcpyDeviceToHost, g_ctx.stream));
     HIPCHK(hipStreamSynchronize(g_ctx.stream));
     uint64_t o = 0;
     for (size_t i = 0; i < q->n_terms.size(); ++i) {
@@ -622,6 +653,32 @@ extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_has
 }
 
 // ------------------------------------------------------------------- search
+static int get_event(size_t i, hipEvent_t* ev) {
+    while (g_ctx.events.size() <= i) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreate(&e));
+        g_ctx.events.push_back(e);
+    }
+    *ev = g_ctx.events[i];
+    return PM_OK;
+}
+static int take_hit_buffer(uint64_t cap, HitBuf* out) {
+    for (size_t i = 0; i < g_ctx.free_hits.size(); ++i)
+        if (g_ctx.free_hits[i].cap >= cap) {
+            *out = g_ctx.free_hits[i];
+            g_ctx.free_hits.erase(g_ctx.free_hits.begin() + (long)i);
+            return PM_OK;
+        }
+    out->cap = cap;
+    HIPCHK(hipMalloc((void**)&out->p, cap * sizeof(uint4)));
+    return PM_OK;
+}
+static void give_hit_buffer(HitBuf b) {
+    if (!b.p) return;
+    if (g_ctx.ready && g_ctx.free_hits.size() < 2) g_ctx.free_hits.push_back(b);
+    else hipFree(b.p);
+}
+
 extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                          double threshold, uint32_t slot_base, pm_result_t** out) {
     NEED_DEV();
@@ -633,105 +690,143 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
             return fail(PM_EINVAL, "index %zu has term_size %u but the queries were parsed for %u", s, idx[s]->info.term_size, q->k);
     }
     const size_t nq = q->headers.size();
-    pm_result* r = new pm_result();
-    r->st.n_queries = nq; r->st.n_terms = q->total_terms;
     hipStream_t st = g_ctx.stream;
 
-    // per-query minimum score
-    std::vector<uint32_t> thr(nq);
-    for (size_t i = 0; i < nq; ++i) thr[i] = threshold == 0.0 ? 0u : pm_threshold_terms(threshold, q->n_terms[i]);
-    uint32_t* d_thr = nullptr; uint32_t* d_rows = nullptr; unsigned long long* d_cnt = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    std::vector<hipEvent_t> sev;
-    uint32_t max_nh = 1;
-    for (size_t s = 0; s < n_idx; ++s) max_nh = std::max(max_nh, idx[s]->info.num_hashes);
-    int rc = PM_OK;
-    auto cleanup = [&]() {
-        if (d_thr) hipFree(d_thr);
-        if (d_rows) hipFree(d_rows);
-        if (d_cnt) hipFree(d_cnt);
-        if (ev0) hipEventDestroy(ev0);
-        if (ev1) hipEventDestroy(ev1);
-        if (ev2) hipEventDestroy(ev2);
-        for (auto e : sev) hipEventDestroy(e);
-    };
+    // ---- launch plan: one scan launch per (lanes-per-row class, canonicalize,
+    // num_hashes) x counter-width class covers every batch of that class;
+    // rows wider than 1024 B (column slabs) get a launch of their own.
+    struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; };
+    std::vector<Group> groups;
+    for (size_t s = 0; s < n_idx; ++s) {
+        const pm_index* ix = idx[s];
+        Group* gp = nullptr;
+        if (ix->slabs == 1)
+            for (auto& g : groups)
+                if (g.slabs == 1 && g.g == ix->g && g.canon == (int)ix->info.canonicalize && g.nh == ix->info.num_hashes) gp = &g;
+        if (!gp) { groups.push_back({ix->g, (int)ix->info.canonicalize, ix->info.num_hashes, ix->slabs, {}}); gp = &groups.back(); }
+        gp->members.push_back(s);
+    }
+    // ---- workspace (persistent, grow-only)
+    if (!g_ctx.d_cnt) HIPCHK(hipMalloc((void**)&g_ctx.d_cnt, 8));
+    if (g_ctx.desc_cap < n_idx) {
+        if (g_ctx.d_desc) hipFree(g_ctx.d_desc);
+        if (g_ctx.h_desc) hipHostFree(g_ctx.h_desc);
+        g_ctx.d_desc = nullptr; g_ctx.h_desc = nullptr; g_ctx.desc_cap = 0;
+        const size_t cap = std::max<size_t>(n_idx, 64);
+        HIPCHK(hipMalloc((void**)&g_ctx.d_desc, cap * sizeof(BatchDesc)));
+        HIPCHK(hipHostMalloc((void**)&g_ctx.h_desc, cap * sizeof(BatchDesc), hipHostMallocDefault));
+        g_ctx.desc_cap = cap;
+    }
+    {
+        size_t o = 0;
+        for (auto& g : groups)
+            for (size_t s : g.members) {
+                const pm_index* ix = idx[s];
+                BatchDesc& d = g_ctx.h_desc[o++];
+                d.matrix = ix->d_matrix; d.stride = ix->info.stride; d.sig_size = ix->info.signature_size;
+                d.barrett_m = barrett_m(ix->info.signature_size); d.n_docs = ix->info.n_docs;
+                d.slot = slot_base + (uint32_t)s; d.pad_ = 0;
+            }
+        HIPCHK(hipMemcpyAsync(g_ctx.d_desc, g_ctx.h_desc, n_idx * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
+    }
+    // per-query minimum score, cached on the query set per threshold value
+    if (nq && (!q->d_thr || q->thr_for != threshold)) {
+        std::vector<uint32_t> thr(nq);
+        for (size_t i = 0; i < nq; ++i) thr[i] = threshold == 0.0 ? 0u : pm_threshold_terms(threshold, q->n_terms[i]);
+        if (!q->d_thr) HIPCHK(hipMalloc((void**)&q->d_thr, nq * 4));
+        HIPCHK(hipMemcpy(q->d_thr, thr.data(), nq * 4, hipMemcpyHostToDevice));
+        q->thr_for = threshold;
+    }
+
+    pm_result* r = new pm_result();
+    r->st.n_queries = nq; r->st.n_terms = q->total_terms;
+    HitBuf hb{nullptr, 0};
+    auto bail = [&](int code) { give_hit_buffer(hb); delete r; return code; };
 #define SCHK(expr)                                                                         \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess) {                                                            \
-            cleanup(); pm_result_free(r);                                                  \
-            return fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-        }                                                                                  \
+        if (e_ != hipSuccess)                                                              \
+            return bail(fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
     } while (0)
-    SCHK(hipMalloc((void**)&d_thr, std::max<size_t>(nq, 1) * 4));
-    SCHK(hipMalloc((void**)&d_rows, std::max<uint64_t>(q->n_slots * max_nh, 8) * 4));
-    SCHK(hipMalloc((void**)&d_cnt, 8));
-    SCHK(hipEventCreate(&ev0)); SCHK(hipEventCreate(&ev1)); SCHK(hipEventCreate(&ev2));
-    sev.resize(n_idx * 2, nullptr);
-    for (auto& e : sev) SCHK(hipEventCreate(&e));
-    if (nq) SCHK(hipMemcpyAsync(d_thr, thr.data(), nq * 4, hipMemcpyHostToDevice, st));
+#define RCHK(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
 
-    r->cap = std::max<uint64_t>(1u << 20, (uint64_t)nq * 16);
+    uint64_t want_cap = std::max<uint64_t>(1u << 20, (uint64_t)nq * 16);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        SCHK(hipMalloc((void**)&r->d_hits, r->cap * sizeof(uint4)));
-        SCHK(hipMemsetAsync(d_cnt, 0, 8, st));
+        RCHK(take_hit_buffer(want_cap, &hb));
+        r->launches.clear();
+        q->epoch++;                       // hashes are part of the job: recomputed by every search
+        size_t nev = 0;
+        hipEvent_t ev0, ev1, ev2;
+        RCHK(get_event(nev++, &ev0)); RCHK(get_event(nev++, &ev1)); RCHK(get_event(nev++, &ev2));
+        SCHK(hipMemsetAsync(g_ctx.d_cnt, 0, 8, st));
         SCHK(hipEventRecord(ev0, st));
-        uint64_t alg = 0;
-        // hashes are recomputed by every pm_search call (one job = hash + scan);
-        // within the call they are shared by all indexes with equal (canonicalize, num_hashes)
-        q->hash_canon = -1;
-        rc = ensure_hashes(q, (int)idx[0]->info.canonicalize, idx[0]->info.num_hashes);
-        if (rc) { cleanup(); pm_result_free(r); return rc; }
+        uint64_t* d_h = nullptr;
+        for (auto& g : groups) RCHK(ensure_hashes(q, g.canon, g.nh, &d_h));
         SCHK(hipEventRecord(ev1, st));
-        for (size_t s = 0; s < n_idx; ++s) {
-            const pm_index* ix = idx[s];
-            const int canon = (int)ix->info.canonicalize; const uint32_t nh = ix->info.num_hashes;
-            rc = ensure_hashes(q, canon, nh);
-            if (rc) { cleanup(); pm_result_free(r); return rc; }
-            SCHK(launch_map_rows(q->d_hashes, q->n_slots * nh, ix->info.signature_size, d_rows, st));
-            SCHK(hipEventRecord(sev[2 * s], st));
+        uint64_t alg = 0;
+        size_t desc_off = 0;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> lev;
+        for (auto& g : groups) {
+            RCHK(ensure_hashes(q, g.canon, g.nh, &d_h));
+            uint64_t rowsum = 0;
+            for (size_t s : g.members) rowsum += idx[s]->info.row_bytes;
             for (int c = 0; c < 4; ++c) {
                 const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
                 if (e == b) continue;
                 ScanArgs a;
-                a.matrix = ix->d_matrix; a.stride = ix->info.stride; a.rows = d_rows;
-                a.qd = q->d_qd; a.thr = d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
-                a.n_docs = ix->info.n_docs; a.nh = nh; a.slot = slot_base + (uint32_t)s;
-                a.hits = r->d_hits; a.hit_count = d_cnt; a.hit_cap = r->cap;
-                SCHK(launch_scan(a, ix->g, kPlaneClass[c], ix->slabs, st));
-                r->st.n_scan_launches += 1;
+                a.batches = g_ctx.d_desc + desc_off; a.n_batches = (uint32_t)g.members.size();
+                const uint32_t qpb = scan_queries_per_block(g.g);
+                a.tiles = (e - b + qpb - 1) / qpb;
+                a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
+                a.flags = g_scan_flags;
+                a.nh = g.nh; a.hits = hb.p; a.hit_count = g_ctx.d_cnt; a.hit_cap = hb.cap;
+                if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
+                    return bail(fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches));
+                hipEvent_t es, ee;
+                RCHK(get_event(nev++, &es)); RCHK(get_event(nev++, &ee));
+                SCHK(hipEventRecord(es, st));
+                SCHK(launch_scan(a, g.g, kPlaneClass[c], g.slabs, st));
+                SCHK(hipEventRecord(ee, st));
+                lev.push_back({es, ee});
+                uint64_t terms = 0;
+                for (uint32_t i = b; i < e; ++i) terms += q->n_terms[q->qmap[i]];
+                pm_launch_t L{};
+                L.lanes_per_row = (uint32_t)g.g; L.planes = (uint32_t)kPlaneClass[c]; L.num_hashes = g.nh;
+                L.n_batches = a.n_batches; L.n_queries = e - b;
+                L.algorithmic_bytes = terms * g.nh * rowsum;
+                r->launches.push_back(L);
+                alg += L.algorithmic_bytes;
             }
-            SCHK(hipEventRecord(sev[2 * s + 1], st));
-            alg += q->total_terms * nh * ix->info.row_bytes;
+            desc_off += g.members.size();
         }
         SCHK(hipEventRecord(ev2, st));
         unsigned long long cnt = 0;
-        SCHK(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        SCHK(hipMemcpyAsync(&cnt, g_ctx.d_cnt, 8, hipMemcpyDeviceToHost, st));
         SCHK(hipStreamSynchronize(st));
         r->st.algorithmic_bytes = alg;
-        if (cnt <= r->cap) {
+        r->st.n_scan_launches = (uint32_t)r->launches.size();
+        if (cnt <= hb.cap) {
             r->n_hits = cnt;
             float ms = 0;
             SCHK(hipEventElapsedTime(&ms, ev0, ev2)); r->st.ms_total = ms;
             SCHK(hipEventElapsedTime(&ms, ev0, ev1)); r->st.ms_hash = ms;
             double scan = 0;
-            r->scan_ms.resize(n_idx);
-            for (size_t s = 0; s < n_idx; ++s) {
-                SCHK(hipEventElapsedTime(&ms, sev[2 * s], sev[2 * s + 1]));
-                r->scan_ms[s] = ms; scan += ms;
+            for (size_t i = 0; i < lev.size(); ++i) {
+                SCHK(hipEventElapsedTime(&ms, lev[i].first, lev[i].second));
+                r->launches[i].ms = ms; scan += ms;
             }
             r->st.ms_scan = scan;
             break;
         }
-        // hit buffer too small: grow to the exact count and run again
-        if (attempt == 1) { cleanup(); pm_result_free(r); return fail(PM_EHIP, "hit count changed between runs"); }
-        hipFree(r->d_hits); r->d_hits = nullptr;
-        r->cap = cnt;
-        r->st.n_scan_launches = 0;
+        // hit buffer too small: grow to the exact count and run the job again
+        if (attempt == 1) return bail(fail(PM_EHIP, "hit count changed between runs"));
+        hipFree(hb.p); hb = HitBuf{nullptr, 0};
+        want_cap = cnt;
     }
 #undef SCHK
+#undef RCHK
+    r->d_hits = hb.p; r->cap = hb.cap;
     r->st.n_hits = r->n_hits;
-    cleanup();
     *out = r;
     return PM_OK;
 }
@@ -741,9 +836,10 @@ extern "C" int pm_result_stats(const pm_result_t* r, pm_stats_t* st) {
     *st = r->st;
     return PM_OK;
 }
-extern "C" int pm_result_scan_ms(const pm_result_t* r, double* ms, size_t n) {
-    if (!r || !ms || n != r->scan_ms.size()) return fail(PM_EINVAL, "bad argument");
-    for (size_t i = 0; i < n; ++i) ms[i] = r->scan_ms[i];
+extern "C" int pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size_t* n) {
+    if (!r || !n) return fail(PM_EINVAL, "bad argument");
+    *n = r->launches.size();
+    if (out) for (size_t i = 0; i < r->launches.size() && i < cap; ++i) out[i] = r->launches[i];
     return PM_OK;
 }
 extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n) {
@@ -770,8 +866,36 @@ static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
     return a.doc < b.doc;                                 // then document index ascending
 }
 
+// Orders records by (slot, query, score desc, doc asc).  Large inputs: stable
+// LSD radix passes on the (slot, query) key, then a comparison sort inside each
+// (slot, query) run (runs are short: the hits of one query in one batch).
+static void order_hits(pm_hit_t* h, uint64_t n) {
+    if (n < 4096) { std::sort(h, h + n, hit_less); return; }
+    uint64_t maxkey = 0;
+    for (uint64_t i = 0; i < n; ++i) maxkey |= ((uint64_t)h[i].slot << 32) | h[i].query;
+    std::vector<pm_hit_t> tmp((size_t)n);
+    pm_hit_t* src = h; pm_hit_t* dst = tmp.data();
+    std::vector<uint64_t> cnt(1 << 11);
+    for (int shift = 0; shift < 64 && (maxkey >> shift) != 0; shift += 11) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (uint64_t i = 0; i < n; ++i) cnt[((((uint64_t)src[i].slot << 32) | src[i].query) >> shift) & 2047]++;
+        uint64_t sum = 0;
+        for (auto& c : cnt) { uint64_t t = c; c = sum; sum += t; }
+        for (uint64_t i = 0; i < n; ++i) dst[cnt[((((uint64_t)src[i].slot << 32) | src[i].query) >> shift) & 2047]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != h) memcpy(h, src, (size_t)n * sizeof(pm_hit_t));
+    uint64_t b = 0;
+    while (b < n) {
+        uint64_t e = b + 1;
+        while (e < n && h[e].slot == h[b].slot && h[e].query == h[b].query) ++e;
+        if (e - b > 1) std::sort(h + b, h + e, hit_less);
+        b = e;
+    }
+}
+
 extern "C" void pm_hits_sort(pm_hit_t* hits, uint64_t n) {
-    if (hits && n) std::sort(hits, hits + n, hit_less);
+    if (hits && n) order_hits(hits, n);
 }
 
 extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {
@@ -783,7 +907,7 @@ extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64
             HIPCHK(hipMemcpyAsync(r->host.data(), r->d_hits, r->n_hits * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.stream));
             HIPCHK(hipStreamSynchronize(g_ctx.stream));
         }
-        std::sort(r->host.begin(), r->host.end(), hit_less);
+        order_hits(r->host.data(), r->host.size());
         r->host_ready = true;
     }
     *hits = r->host.data(); *n = r->n_hits;
@@ -791,7 +915,7 @@ extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64
 }
 extern "C" void pm_result_free(pm_result_t* r) {
     if (!r) return;
-    if (r->d_hits) hipFree(r->d_hits);
+    give_hit_buffer(HitBuf{r->d_hits, r->cap});
     delete r;
 }
 
@@ -812,7 +936,7 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
     for (const pm_hit_t& h : mine)
         if (h.query >= nq || h.doc >= ix->info.n_docs)
             return fail(PM_EINVAL, "hit record (query %u, doc %u) out of range for this index/query set", h.query, h.doc);
-    std::sort(mine.begin(), mine.end(), hit_less);
+    order_hits(mine.data(), mine.size());
     std::string out;
     out.reserve(mine.size() * 24 + nq * 24);
     char num[32];

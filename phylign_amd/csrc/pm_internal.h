@@ -14,17 +14,29 @@ struct QDesc {
     uint32_t seq_lo, seq_hi;   // byte offset of the sequence in the packed buffer
 };
 
+// One resident batch index as the scan kernel sees it (48 B, read through the
+// scalar cache: the batch is uniform per workgroup).
+struct BatchDesc {
+    const uint8_t* matrix;      // row r at matrix + r*stride, 16-B aligned
+    uint64_t stride;
+    uint64_t sig_size;          // S
+    uint64_t barrett_m;         // floor(2^64 / S); 0 encodes S == 1
+    uint32_t n_docs;
+    uint32_t slot;
+    uint64_t pad_;
+};
+
 struct ScanArgs {
-    const uint8_t*  matrix;     // row r at matrix + r*stride, 16-B aligned
-    uint64_t        stride;
-    const uint32_t* rows;       // [blk][hash j][8] row indices of this batch
+    const BatchDesc* batches;   // batches of this launch (same lanes-per-row class)
+    uint32_t        n_batches;
+    uint32_t        tiles;      // workgroups per batch; blockIdx.x = batch*tiles + tile
+    const uint64_t* hashes;     // [blk][hash j][8]
     const QDesc*    qd;
     const uint32_t* thr;        // per query minimum score (0 = keep all)
     const uint32_t* qmap;       // launch-local index -> query id
     uint32_t        nq;         // queries in this launch
-    uint32_t        n_docs;
     uint32_t        nh;
-    uint32_t        slot;
+    uint32_t        flags;      // bit0: non-temporal row loads (experiment)
     uint4*          hits;       // pm_hit_t records
     unsigned long long* hit_count;
     uint64_t        hit_cap;
@@ -34,10 +46,11 @@ struct ScanArgs {
 hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t* blk_query,
                              uint64_t n_slots, uint32_t k, int canon, uint32_t nh,
                              uint64_t* hashes, hipStream_t st);
-hipError_t launch_map_rows(const uint64_t* hashes, uint64_t n, uint64_t sig_size,
-                           uint32_t* rows, hipStream_t st);
-// g = lanes per row (1..64 pow2), planes = counter bit planes (7,10,16,24)
+// g = lanes per row (1..64 pow2), planes = counter bit planes (7,10,16,24);
+// slabs > 1 only with n_batches == 1 (rows wider than 1024 B)
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st);
+uint32_t scan_queries_per_block(int g);
+uint64_t barrett_m(uint64_t S);
 hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst, uint64_t stride,
                            uint64_t n_rows, hipStream_t st);
 hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs,

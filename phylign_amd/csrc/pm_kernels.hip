@@ -6,10 +6,11 @@
 // random row gather plus bit-sliced counting, bounded by HBM.
 //
 //   k_hash_terms  a5  canonicalise each k-mer + XXH64(seed j)
-//   k_map_rows    a5  row = hash % signature_size (Barrett, exact)
-//   k_scan        a6  gather rows (16 B per lane, G lanes per row), AND over
+//   k_scan        a5  row = hash % signature_size (Barrett, exact), fused
+//                 a6  gather rows (16 B per lane, G lanes per row), AND over
 //                     hash functions, carry-save bit-sliced per-document counts
 //                 a7  bit-sliced ">= threshold", ballot/mbcnt compaction of hits
+//                 one launch covers every resident batch of one row-width class
 //   k_restride / k_synth / k_plant   index residency helpers (a4)
 #include "pm_internal.h"
 
@@ -38,7 +39,8 @@ __device__ __forceinline__ uint32_t comp_base(uint32_t c) { return c ^ ((c & 2u)
 struct KmerView {
     const uint8_t* p; uint32_t k; bool rc;
     __device__ __forceinline__ uint64_t byte(uint32_t i) const {
-        return rc ? (uint64_t)comp_base(p[k - 1 - i]) : (uint64_t)p[i];
+        const uint32_t c = p[rc ? k - 1 - i : i];       // one load, no divergent branch
+        return (uint64_t)(rc ? comp_base(c) : c);
     }
     __device__ __forceinline__ uint64_t le64(uint32_t i) const {
         uint64_t v = 0;
@@ -75,7 +77,43 @@ __device__ uint64_t xxh64_kmer(const KmerView& kv, uint64_t seed) {
     return h;
 }
 
+// ---- k <= 32: the whole k-mer lives in four 64-bit registers ---------------
+// bytewise complement of 8 packed bases (same rule as comp_base)
+__device__ __forceinline__ uint64_t comp64(uint64_t w) {
+    const uint64_t m = (w >> 1) & 0x0101010101010101ULL;
+    return w ^ 0x1515151515151515ULL ^ (m | (m << 4));
+}
+__device__ __forceinline__ uint64_t low_bytes_mask(int nbytes) {   // nbytes in [0, 8]
+    return nbytes >= 8 ? ~0ULL : ((1ULL << (8 * (nbytes < 0 ? 0 : nbytes))) - 1ULL);
+}
+// XXH64 of the first k (<= 32) bytes held little-endian in w[0..3]
+__device__ __forceinline__ uint64_t xxh64_words(const uint64_t w[4], uint32_t k, uint64_t seed) {
+    uint64_t h;
+    uint32_t i = 0;
+    if (k == 32) {
+        uint64_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        v1 = xround(v1, w[0]); v2 = xround(v2, w[1]); v3 = xround(v3, w[2]); v4 = xround(v4, w[3]);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+        h += 32;
+        i = 32;
+    } else {
+        h = seed + XP5 + (uint64_t)k;
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            if (i + 8 <= k) { h ^= xround(0, w[n]); h = rotl64(h, 27) * XP1 + XP4; i += 8; }
+    }
+    uint64_t rem = (i == 0) ? w[0] : (i == 8) ? w[1] : (i == 16) ? w[2] : (i == 24) ? w[3] : 0ULL;
+    uint32_t left = k - i;
+    if (left >= 4) { h ^= (rem & 0xFFFFFFFFULL) * XP1; h = rotl64(h, 23) * XP2 + XP3; rem >>= 32; left -= 4; }
+    for (; left; --left) { h ^= (rem & 0xFFULL) * XP5; h = rotl64(h, 11) * XP1; rem >>= 8; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
+
 // One thread per padded term slot.  hashes layout: [8-slot block][hash j][8].
+// The packed sequence buffer is padded by 64 bytes so aligned 8-byte reads
+// around a k-mer never leave the allocation.
 __global__ __launch_bounds__(256) void k_hash_terms(
     const uint8_t* __restrict__ seq, const QDesc* __restrict__ qd,
     const uint32_t* __restrict__ blk_query, uint64_t n_slots, uint32_t k, int canon,
@@ -91,8 +129,53 @@ __global__ __launch_bounds__(256) void k_hash_terms(
         for (uint32_t j = 0; j < nh; ++j) out[j * 8] = 0;
         return;
     }
+    const uint64_t off = (((uint64_t)d.seq_hi << 32) | d.seq_lo) + t;
+    if (k <= 32) {
+        // five aligned 8-byte loads, funnel-shifted to the k-mer's first byte
+        const uint64_t* ap = reinterpret_cast<const uint64_t*>(seq + (off & ~7ULL));
+        const uint32_t sh8 = (uint32_t)(off & 7ULL) * 8;
+        const uint64_t a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+        uint64_t f[4];
+        if (sh8) {
+            f[0] = (a0 >> sh8) | (a1 << (64 - sh8)); f[1] = (a1 >> sh8) | (a2 << (64 - sh8));
+            f[2] = (a2 >> sh8) | (a3 << (64 - sh8)); f[3] = (a3 >> sh8) | (a4 << (64 - sh8));
+        } else { f[0] = a0; f[1] = a1; f[2] = a2; f[3] = a3; }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) f[n] &= low_bytes_mask((int)k - 8 * n);
+        uint64_t w[4] = {f[0], f[1], f[2], f[3]};
+        if (canon) {
+            // reverse complement: complement bytewise, reverse the 32-byte buffer,
+            // then drop the 32-k leading (formerly trailing) bytes
+            uint64_t r[6];
+            r[0] = __builtin_bswap64(comp64(f[3])); r[1] = __builtin_bswap64(comp64(f[2]));
+            r[2] = __builtin_bswap64(comp64(f[1])); r[3] = __builtin_bswap64(comp64(f[0]));
+            r[4] = 0; r[5] = 0;
+            const uint32_t drop = 32 - k;
+            if (drop & 16) { r[0] = r[2]; r[1] = r[3]; r[2] = 0; r[3] = 0; }
+            if (drop & 8)  { r[0] = r[1]; r[1] = r[2]; r[2] = r[3]; r[3] = 0; }
+            const uint32_t b8 = (drop & 7) * 8;
+            uint64_t rc[4];
+            if (b8) {
+                rc[0] = (r[0] >> b8) | (r[1] << (64 - b8)); rc[1] = (r[1] >> b8) | (r[2] << (64 - b8));
+                rc[2] = (r[2] >> b8) | (r[3] << (64 - b8)); rc[3] = (r[3] >> b8);
+            } else { rc[0] = r[0]; rc[1] = r[1]; rc[2] = r[2]; rc[3] = r[3]; }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) rc[n] &= low_bytes_mask((int)k - 8 * n);
+            // lexicographic order of the byte strings = order of the byte-swapped words
+            bool use_rc = false, decided = false;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint64_t a = __builtin_bswap64(f[n]), b = __builtin_bswap64(rc[n]);
+                if (!decided && a != b) { use_rc = b < a; decided = true; }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) w[n] = use_rc ? rc[n] : f[n];
+        }
+        for (uint32_t j = 0; j < nh; ++j) out[j * 8] = xxh64_words(w, k, (uint64_t)j);
+        return;
+    }
     KmerView kv;
-    kv.p = seq + (((uint64_t)d.seq_hi << 32) | d.seq_lo) + t;
+    kv.p = seq + off;
     kv.k = k; kv.rc = false;
     if (canon) {
         // lexicographic min(kmer, revcomp): first position where they differ decides
@@ -104,22 +187,20 @@ __global__ __launch_bounds__(256) void k_hash_terms(
     for (uint32_t j = 0; j < nh; ++j) out[j * 8] = xxh64_kmer(kv, (uint64_t)j);
 }
 
-// row = h % S, exact: Barrett with m = floor(2^64 / S) and at most two fix-ups.
-__global__ __launch_bounds__(256) void k_map_rows(
-    const uint64_t* __restrict__ hashes, uint64_t n, uint64_t S, uint64_t m,
-    uint32_t* __restrict__ rows)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t h = hashes[i];
-    uint64_t r;
-    if (S == 1) r = 0;
-    else {
-        const uint64_t qh = __umul64hi(h, m);
-        r = h - qh * S;
-        while (r >= S) r -= S;
-    }
-    rows[i] = (uint32_t)r;
+// row = h % S, exact: Barrett with m = floor(2^64 / S) and at most two fix-ups
+// (q' = mulhi(h, m) >= floor(h/S) - 1).  m == 0 encodes S == 1.
+__device__ __forceinline__ uint64_t mod_sig(uint64_t h, uint64_t S, uint64_t m) {
+    const uint64_t qh = __umul64hi(h, m);
+    uint64_t r = h - qh * S;
+    if (r >= S) r -= S;
+    if (r >= S) r -= S;
+    return m ? r : 0ull;
+}
+uint64_t barrett_m(uint64_t S) {
+    if (S < 2) return 0;
+    uint64_t m = ~0ull / S;
+    if ((~0ull % S) + 1 == S) m += 1;   // 2^64 = (2^64 - 1) + 1
+    return m;
 }
 
 // --------------------------------------------------------------------- scan
@@ -150,7 +231,10 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
     constexpr int QPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t li = (blockIdx.x * 4u + (uint32_t)wave) * QPW + (uint32_t)(lane / G);
+    const uint32_t batch = blockIdx.x / a.tiles;
+    const uint32_t tile = blockIdx.x - batch * a.tiles;
+    const BatchDesc bd = a.batches[batch];            // uniform: scalar loads
+    const uint32_t li = (tile * 4u + (uint32_t)wave) * QPW + (uint32_t)(lane / G);
     const uint32_t c = (uint32_t)(lane % G);
     const uint32_t slab = blockIdx.y;
     const uint64_t boff = ((uint64_t)slab * G + c) * 16;   // byte offset of this lane's chunk
@@ -163,14 +247,16 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
         const QDesc d = a.qd[q];
         nt = d.n_terms; pb = d.pad_blk; thr = a.thr[q];
     }
-    const bool active = qv && boff < a.stride;
+    const uint64_t stride = bd.stride;
+    const bool active = qv && boff < stride;
     const uint32_t nblk = active ? (nt + 7u) >> 3 : 0u;
     const uint32_t wmax = wave_max_u32(nblk);
     const uint32_t nh = NH1 ? 1u : a.nh;
 
-    const uint8_t* base = a.matrix + boff;
-    const u32x4* ridx = reinterpret_cast<const u32x4*>(a.rows + pb * nh * 8);
-    const uint64_t stride = a.stride;
+    const uint8_t* base = bd.matrix + boff;
+    const u32x4* hp = reinterpret_cast<const u32x4*>(a.hashes + pb * nh * 8);
+    const uint64_t S = bd.sig_size, bm = bd.barrett_m;
+    const bool ntl = (a.flags & 1u) != 0;
 
     u32x4 pl[P];
 #pragma unroll
@@ -183,15 +269,21 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
         if (b < nblk) {
             const uint32_t left = nt - b * 8u;        // >= 1 valid terms in this block
             for (uint32_t j = 0; j < nh; ++j) {
-                const u32x4 i0 = ridx[(b * nh + j) * 2 + 0];
-                const u32x4 i1 = ridx[(b * nh + j) * 2 + 1];
-                const uint32_t r[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+                const u32x4* hj = hp + (size_t)(b * nh + j) * 4;
+                const u32x4 h0 = hj[0], h1 = hj[1], h2 = hj[2], h3 = hj[3];
+                const uint64_t h[8] = {
+                    ((uint64_t)h0.y << 32) | h0.x, ((uint64_t)h0.w << 32) | h0.z,
+                    ((uint64_t)h1.y << 32) | h1.x, ((uint64_t)h1.w << 32) | h1.z,
+                    ((uint64_t)h2.y << 32) | h2.x, ((uint64_t)h2.w << 32) | h2.z,
+                    ((uint64_t)h3.y << 32) | h3.x, ((uint64_t)h3.w << 32) | h3.z};
                 u32x4 v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = (u32x4)(0u);
-                    if ((uint32_t)i < left)
-                        v[i] = *reinterpret_cast<const u32x4*>(base + (uint64_t)r[i] * stride);
+                    if ((uint32_t)i < left) {
+                        const u32x4* rp = reinterpret_cast<const u32x4*>(base + mod_sig(h[i], S, bm) * stride);
+                        v[i] = ntl ? __builtin_nontemporal_load(rp) : *rp;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = (j == 0) ? v[i] : (x[i] & v[i]);
@@ -235,8 +327,8 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
     for (int w = 0; w < 4; ++w) {
         const uint64_t first = doc0 + 32u * w;
         uint32_t keep;
-        if (!active || first >= a.n_docs) keep = 0u;
-        else if (first + 32 > a.n_docs) keep = (1u << (a.n_docs - first)) - 1u;
+        if (!active || first >= bd.n_docs) keep = 0u;
+        else if (first + 32 > bd.n_docs) keep = (1u << (bd.n_docs - first)) - 1u;
         else keep = 0xFFFFFFFFu;
         mw[w] &= keep;
     }
@@ -271,15 +363,14 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
             const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, (int)src, 64);
             const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), (int)src, 64);
             const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
-            if (has && pos < a.hit_cap) a.hits[pos] = make_uint4(q, doc, score, a.slot);
+            if (has && pos < a.hit_cap) a.hits[pos] = make_uint4(q, doc, score, bd.slot);
         }
     }
 }
 
 template <int G, int P>
 static hipError_t scan_dispatch_nh(const ScanArgs& a, uint32_t slabs, hipStream_t st) {
-    constexpr int QPB = 4 * (64 / G);
-    dim3 grid((a.nq + QPB - 1) / QPB, slabs, 1);
+    dim3 grid(a.n_batches * a.tiles, slabs, 1);
     if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true>), grid, dim3(256), 0, st, a);
     else           hipLaunchKernelGGL((k_scan<G, P, false>), grid, dim3(256), 0, st, a);
     return hipGetLastError();
@@ -294,8 +385,10 @@ static hipError_t scan_dispatch_p(const ScanArgs& a, int planes, uint32_t slabs,
         default: return hipErrorInvalidValue;
     }
 }
+uint32_t scan_queries_per_block(int g) { return 4u * (64u / (uint32_t)g); }
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st) {
-    if (a.nq == 0) return hipSuccess;
+    if (a.nq == 0 || a.n_batches == 0) return hipSuccess;
+    if (slabs > 1 && a.n_batches != 1) return hipErrorInvalidValue;
     switch (g) {
         case 1:  return scan_dispatch_p<1>(a, planes, slabs, st);
         case 2:  return scan_dispatch_p<2>(a, planes, slabs, st);
@@ -315,19 +408,6 @@ hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t
     const uint64_t blocks = (n_slots + 255) / 256;
     hipLaunchKernelGGL(k_hash_terms, dim3((uint32_t)blocks), dim3(256), 0, st,
                        seq, qd, blk_query, n_slots, k, canon, nh, hashes);
-    return hipGetLastError();
-}
-
-hipError_t launch_map_rows(const uint64_t* hashes, uint64_t n, uint64_t S, uint32_t* rows, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    // m = floor(2^64 / S) for S >= 2
-    uint64_t m = 0;
-    if (S >= 2) {
-        m = ~0ull / S;
-        if ((~0ull % S) + 1 == S) m += 1;   // 2^64 = (2^64-1) + 1
-    }
-    const uint64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_map_rows, dim3((uint32_t)blocks), dim3(256), 0, st, hashes, n, S, m, rows);
     return hipGetLastError();
 }
 

@@ -47,12 +47,18 @@ def scale_shapes(shapes, rows_divisor):
                        index_bytes=max(1024, s.signature_size // rows_divisor) * s.row_bytes) for s in shapes]
 
 
+def scan_cost(shape):
+    """relative scan cost of one query k-mer against this batch: HBM moves whole
+    128-byte lines, so a row costs its width rounded up to lines"""
+    return (shape.row_bytes + 127) // 128 * 128
+
+
 def assign_batches(shapes, n_ranks, capacity_bytes=None):
-    """Static batch -> rank map: greedy longest-processing-time on row_bytes (scan
-    work per query k-mer is proportional to the row width), ties broken by index
-    bytes; optional per-rank capacity on the sum of index bytes.  Returns a list
-    of lists of positions into `shapes`, each sorted ascending."""
-    order = sorted(range(len(shapes)), key=lambda i: (-shapes[i].row_bytes, -shapes[i].index_bytes, i))
+    """Static batch -> rank map: greedy longest-processing-time on scan_cost (128-B
+    lines per looked-up row), ties broken by index bytes; optional per-rank
+    capacity on the sum of index bytes.  Returns a list of lists of positions
+    into `shapes`, each sorted ascending."""
+    order = sorted(range(len(shapes)), key=lambda i: (-scan_cost(shapes[i]), -shapes[i].index_bytes, i))
     load = [0] * n_ranks
     used = [0] * n_ranks
     out = [[] for _ in range(n_ranks)]
@@ -64,7 +70,7 @@ def assign_batches(shapes, n_ranks, capacity_bytes=None):
         else:
             raise MemoryError(f"batch {shapes[i].batch} does not fit on any rank")
         out[r].append(i)
-        load[r] += shapes[i].row_bytes
+        load[r] += scan_cost(shapes[i])
         used[r] += shapes[i].index_bytes
     return [sorted(x) for x in out]
 

@@ -67,9 +67,9 @@ def test_assign_batches_is_a_balanced_partition():
         parts = W.assign_batches(shapes, world)
         flat = sorted(i for p in parts for i in p)
         assert flat == list(range(64))
-        loads = [sum(shapes[i].row_bytes for i in p) for p in parts]
-        assert max(loads) - min(loads) <= 500          # at most one widest row apart
-        assert max(loads) <= 16285 / world * 1.08
+        loads = [sum(W.scan_cost(shapes[i]) for i in p) for p in parts]
+        assert max(loads) - min(loads) <= 512          # at most one widest row apart
+        assert max(loads) <= sum(loads) / world * 1.08
     with pytest.raises(MemoryError):
         W.assign_batches(shapes, 2, capacity_bytes=50 * 10**9)
     full = W.select("full")

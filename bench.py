@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--queries", type=int, default=100000)
     ap.add_argument("--qlen", type=int, default=150)
     ap.add_argument("--threshold", type=float, default=0.7)
+    ap.add_argument("--nb-best-hits", type=int, default=100, help="config.yaml:23 nb_best_hits (on-device top-n + ties)")
     ap.add_argument("--rows-divisor", type=int, default=1, help="shrink every batch's row count (quick runs)")
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 compact, 2 line-aligned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +184,7 @@ def main():
 
     def step():
         t_a = time.perf_counter()
-        res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id])
+        res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
         st = res.stats
         buf = torch.empty((int(st.n_hits), 4), dtype=torch.int32, device="cuda")
         t_b = time.perf_counter()
@@ -252,7 +253,8 @@ def main():
                                f"{sum(s.row_bytes for s in shapes)} row bytes per k-mer), "
                                f"{nq} synthetic {args.qlen}-bp queries ({terms_per_q} 31-mers each), threshold {args.threshold}",
                    "batches": len(shapes), "queries": nq, "query_len": args.qlen, "k": 31,
-                   "num_hashes": 1, "threshold": args.threshold, "rows_divisor": args.rows_divisor,
+                   "num_hashes": 1, "threshold": args.threshold, "nb_best_hits": args.nb_best_hits,
+                   "rows_divisor": args.rows_divisor,
                    "sharding": f"{world} rank(s), static LPT batch assignment, one gather of hit records"},
         "hbm_fraction_whole_step": alg_total / (elapsed / args.steps) / (HBM_PEAK_GBPS * 1e9 * world),
         "hits": int(len(last["hits"])) if last["hits"] is not None else None,

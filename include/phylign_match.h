@@ -55,7 +55,12 @@ typedef struct {
     uint32_t has_matrix;       /* 0 for header-only handles */
 } pm_index_info_t;
 
-/* One hit record, 16 bytes; identical in HBM, on the wire (RCCL) and on host. */
+/* One hit record, 16 bytes; identical in HBM, on the wire (RCCL) and on host.
+ * A record with doc == PM_DOC_COUNT is not a hit: it is written once per
+ * (query, slot) whose hit list was cut to the n best on the GPU and carries in
+ * `score` the number of documents that passed the threshold before the cut (the
+ * N that cobs prints in the "*header\tN" line, which postprocess_cobs.py keeps). */
+#define PM_DOC_COUNT 0xFFFFFFFFu
 typedef struct {
     uint32_t query;   /* index of the FASTA record inside the pm_queries_t */
     uint32_t doc;     /* document (column) index inside the batch index */
@@ -108,6 +113,13 @@ int  pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signature_size,
                     int layout, int header_only, pm_index_t** out);
 /* sets bit (rows[i], docs[i]) for i<n: planted hits for parity runs */
 int  pm_index_plant(pm_index_t* idx, const uint64_t* rows, const uint32_t* docs, size_t n);
+/* Measurement aid, not part of the matching path: times a pure random-row
+ * gather over this index with k_scan's access pattern (n_groups row-cooperating
+ * lane groups x lookups_per_group rows each, no counting); *ms = hipEvent time,
+ * *bytes = rows fetched x row_bytes.  Gives the memory-system ceiling the scan
+ * kernel is compared with in DESIGN.md. */
+int  pm_index_probe_gather(const pm_index_t* idx, uint64_t n_groups, uint64_t lookups_per_group,
+                           double* ms, uint64_t* bytes);
 int  pm_index_info(const pm_index_t* idx, pm_index_info_t* info);
 const char* pm_index_doc_name(const pm_index_t* idx, uint32_t doc, size_t* len);
 /* copies the row_bytes logical bytes of one row back to the host (checks) */
@@ -131,10 +143,14 @@ int  pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint6
 /* ---- search (replaces the query loop of `cobs query`) -------------------- */
 /* Scores every query against every index of idx[0..n_idx) and keeps documents
  * with score >= pm_threshold_terms(threshold, terms(query)); threshold 0 keeps
- * all.  Hits stay in HBM until asked for.  slot_base is added to the slot field
- * (global batch numbering across ranks). */
+ * all.  nb_best_hits > 0 additionally keeps, per (query, index), only the
+ * nb_best_hits best documents plus those tied with the last of them -- the
+ * selection rule of scripts/postprocess_cobs.py:31-39, applied on the GPU before
+ * anything leaves HBM (indexes wider than 8192 documents are pruned when the
+ * text is formatted instead).  Hits stay in HBM until asked for.  slot_base is
+ * added to the slot field (global batch numbering across ranks). */
 int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
-               double threshold, uint32_t slot_base, pm_result_t** out);
+               double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out);
 int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
 /* the scan-kernel launches of the search (one per row-width class x counter-width
  * class, each covering all batches of the class) with their hipEvent durations;

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphylign_match.so")
 
 PM_LAYOUT_AUTO, PM_LAYOUT_COMPACT, PM_LAYOUT_ALIGNED = 0, 1, 2
+PM_DOC_COUNT = 0xFFFFFFFF      # doc value of a "count record" (see include/phylign_match.h)
 ERR_NAMES = {-1: "PM_EINVAL", -2: "PM_ENODEV", -3: "PM_ENOMEM", -4: "PM_EIO",
              -5: "PM_EFORMAT", -6: "PM_EQUERY", -7: "PM_EHIP", -8: "PM_ERANGE"}
 
@@ -60,6 +61,7 @@ SYMBOLS = [
     ("pm_index_load_header_mem", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     ("pm_index_synth", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.POINTER(_P)]),
     ("pm_index_plant", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("pm_index_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("pm_index_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
     ("pm_index_doc_name", _P, [_P, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("pm_index_read_row", C.c_int, [_P, C.c_uint64, _P]),
@@ -69,7 +71,7 @@ SYMBOLS = [
     ("pm_queries_terms", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("pm_queries_free", None, [_P]),
     ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
-    ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.POINTER(_P)]),
+    ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("pm_result_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("pm_result_launches", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pm_hits_sort", None, [_P, C.c_uint64]),
@@ -171,6 +173,12 @@ class Index:
         docs = np.ascontiguousarray(docs, dtype=np.uint32)
         assert rows.size == docs.size
         _chk(load().pm_index_plant(self._h, rows.ctypes.data, docs.ctypes.data, rows.size))
+
+    def probe_gather(self, n_groups, lookups_per_group):
+        """(ms, algorithmic bytes) of a pure random-row gather with k_scan's access pattern"""
+        ms, nb = C.c_double(), C.c_uint64()
+        _chk(load().pm_index_probe_gather(self._h, n_groups, lookups_per_group, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
 
     @property
     def info(self):
@@ -288,10 +296,11 @@ class Result:
             pass
 
 
-def search(indexes, queries: Queries, threshold: float, slot_base=0) -> Result:
+def search(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hits=0) -> Result:
+    """nb_best_hits > 0: per (query, index) keep the n best documents + ties (on the GPU)"""
     arr = (_P * len(indexes))(*[ix._h for ix in indexes])
     h = _P()
-    _chk(load().pm_search(arr, len(indexes), queries._h, threshold, slot_base, C.byref(h)))
+    _chk(load().pm_search(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
     return Result(h)
 
 

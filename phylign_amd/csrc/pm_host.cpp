@@ -467,6 +467,29 @@ extern "C" int pm_index_plant(pm_index_t* ix, const uint64_t* rows, const uint32
     return PM_OK;
 }
 
+extern "C" int pm_index_probe_gather(const pm_index_t* ix, uint64_t n_groups, uint64_t lookups_per_group,
+                                     double* ms, uint64_t* bytes) {
+    NEED_DEV();
+    if (!ix || !ix->d_matrix || !ms || !bytes || n_groups == 0) return fail(PM_EINVAL, "bad argument");
+    if (ix->slabs != 1) return fail(PM_EINVAL, "probe supports rows up to 1024 bytes");
+    lookups_per_group = (lookups_per_group + 7) / 8 * 8;
+    uint32_t* sink = nullptr;
+    HIPCHK(hipMalloc((void**)&sink, 4));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipError_t e = hipEventRecord(e0, g_ctx.stream);
+    if (e == hipSuccess) e = launch_probe_gather(ix->d_matrix, ix->info.stride, ix->info.signature_size, ix->g,
+                                                 n_groups, lookups_per_group, sink, g_ctx.stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, g_ctx.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+    float f = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&f, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    if (e != hipSuccess) return fail(PM_EHIP, "probe: %s", hipGetErrorString(e));
+    *ms = f; *bytes = n_groups * lookups_per_group * ix->info.row_bytes;
+    return PM_OK;
+}
+
 extern "C" int pm_index_info(const pm_index_t* ix, pm_index_info_t* info) {
     if (!ix || !info) return fail(PM_EINVAL, "bad argument");
     *info = ix->info;
@@ -680,7 +703,7 @@ static void give_hit_buffer(HitBuf b) {
 }
 
 extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
-                         double threshold, uint32_t slot_base, pm_result_t** out) {
+                         double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
     NEED_DEV();
     if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
     if (!(threshold >= 0.0)) return fail(PM_EINVAL, "threshold must be >= 0");
@@ -779,6 +802,7 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                 a.tiles = (e - b + qpb - 1) / qpb;
                 a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
                 a.flags = g_scan_flags;
+                a.prune_n = nb_best_hits;
                 a.nh = g.nh; a.hits = hb.p; a.hit_count = g_ctx.d_cnt; a.hit_cap = hb.cap;
                 if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
                     return bail(fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches));
@@ -862,6 +886,8 @@ extern "C" int pm_result_copy_hits_device(const pm_result_t* r, void* dst, uint6
 static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
     if (a.slot != b.slot) return a.slot < b.slot;
     if (a.query != b.query) return a.query < b.query;
+    const bool am = a.doc == PM_DOC_COUNT, bm = b.doc == PM_DOC_COUNT;
+    if (am != bm) return am;                              // the count record leads its (slot, query) run
     if (a.score != b.score) return a.score > b.score;     // score descending
     return a.doc < b.doc;                                 // then document index ascending
 }
@@ -934,7 +960,7 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
     std::vector<pm_hit_t> mine;
     for (uint64_t i = 0; i < n_hits; ++i) if (hits[i].slot == slot) mine.push_back(hits[i]);
     for (const pm_hit_t& h : mine)
-        if (h.query >= nq || h.doc >= ix->info.n_docs)
+        if (h.query >= nq || (h.doc >= ix->info.n_docs && h.doc != PM_DOC_COUNT))
             return fail(PM_EINVAL, "hit record (query %u, doc %u) out of range for this index/query set", h.query, h.doc);
     order_hits(mine.data(), mine.size());
     std::string out;
@@ -944,8 +970,10 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
     for (size_t qi = 0; qi < nq; ++qi) {
         size_t e = p;
         while (e < mine.size() && mine[e].query == qi) ++e;
+        size_t total = e - p;
+        if (p < e && mine[p].doc == PM_DOC_COUNT) { total = mine[p].score; ++p; }   // pruned on the GPU
         out.push_back('*'); out += q->headers[qi];
-        out.append(num, (size_t)snprintf(num, sizeof num, "\t%zu\n", e - p));
+        out.append(num, (size_t)snprintf(num, sizeof num, "\t%zu\n", total));
         uint32_t min_kmers = 0;
         for (size_t i = p; i < e; ++i) {
             const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
@@ -992,7 +1020,7 @@ extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len
     const pm_hit_t* hits = nullptr; uint64_t n = 0;
     if (nq) {
         pm_index_t* arr[1] = {ix};
-        rc = pm_search(arr, 1, q, threshold, 0, &r);
+        rc = pm_search(arr, 1, q, threshold, nb_best > 0 ? (uint32_t)std::min<int64_t>(nb_best, 0xFFFFFFFFll) : 0u, 0, &r);
         if (rc == PM_OK) rc = pm_result_hits_host(r, &hits, &n);
     }
     if (rc == PM_OK) rc = pm_format_hits(ix, q, hits, n, 0, nb_best, text, len);

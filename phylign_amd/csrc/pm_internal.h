@@ -37,6 +37,7 @@ struct ScanArgs {
     uint32_t        nq;         // queries in this launch
     uint32_t        nh;
     uint32_t        flags;      // bit0: non-temporal row loads (experiment)
+    uint32_t        prune_n;    // > 0: keep the n best documents (+ ties) per (query, batch)
     uint4*          hits;       // pm_hit_t records
     unsigned long long* hit_count;
     uint64_t        hit_cap;
@@ -55,6 +56,8 @@ hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst,
                            uint64_t n_rows, hipStream_t st);
 hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs,
                         uint64_t seed, uint32_t batch, hipStream_t st);
+hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
+                               uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st);
 hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
                         uint64_t n, hipStream_t st);
 

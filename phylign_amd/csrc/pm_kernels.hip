@@ -306,31 +306,76 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
         }
     }
 
-    // ---- a7: score >= thr, bit-sliced.  carry-out of score + (2^P - thr).
-    u32x4 mask;
-    if (thr == 0u) mask = (u32x4)(0xFFFFFFFFu);
-    else if (thr > nt) mask = (u32x4)(0u);
-    else {
-        const uint32_t K = (1u << P) - thr;
+    // ---- a7: score >= thr, bit-sliced: carry-out of score + (2^P - thr).
+    // valid-document mask first (row padding, inactive lanes)
+    const uint64_t doc0 = ((uint64_t)slab * G + c) * 128;
+    u32x4 valid;
+    {
+        uint32_t kw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t first = doc0 + 32u * w;
+            if (!active || first >= bd.n_docs) kw[w] = 0u;
+            else if (first + 32 > bd.n_docs) kw[w] = (1u << (bd.n_docs - first)) - 1u;
+            else kw[w] = 0xFFFFFFFFu;
+        }
+        valid = (u32x4){kw[0], kw[1], kw[2], kw[3]};
+    }
+    auto ge_mask = [&](uint32_t t) -> u32x4 {          // documents with score >= t (t per lane)
+        if (t == 0u) return valid;
+        if (t > nt) return (u32x4)(0u);
+        const uint32_t K = (1u << P) - t;
         u32x4 cy = (u32x4)(0u);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const u32x4 both = pl[p] & cy, any = pl[p] | cy;
             cy = ((K >> p) & 1u) ? any : both;
         }
-        mask = cy;
-    }
-    // drop columns >= n_docs (row padding) and inactive lanes
-    const uint64_t doc0 = ((uint64_t)slab * G + c) * 128;
-    uint32_t mw[4] = {mask.x, mask.y, mask.z, mask.w};
+        return cy & valid;
+    };
+    u32x4 mask = ge_mask(thr);
+
+    // ---- a8 fused: keep the n best documents plus ties with the n-th
+    // (scripts/postprocess_cobs.py:31-39): raise the cut to the n-th largest score
+    // when more than n documents passed.  The G lanes of a query reduce their
+    // popcounts by xor-shuffles; the search for the cut is a bisection on the score.
+    bool count_rec = false;          // lane 0 of a pruned query reports the unpruned count
+    uint32_t full_count = 0;
+    if (a.prune_n > 0u && gridDim.y == 1) {
+        auto group_count = [&](const u32x4& m) -> uint32_t {
+            uint32_t v = (uint32_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t first = doc0 + 32u * w;
-        uint32_t keep;
-        if (!active || first >= bd.n_docs) keep = 0u;
-        else if (first + 32 > bd.n_docs) keep = (1u << (bd.n_docs - first)) - 1u;
-        else keep = 0xFFFFFFFFu;
-        mw[w] &= keep;
+            for (int o = G / 2; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+            return v;
+        };
+        full_count = group_count(mask);
+        const bool need = full_count > a.prune_n;
+        count_rec = need && c == 0u;
+        uint32_t lo = thr, hi = nt + 1u;                 // count(>= lo) >= n, count(>= hi) < n
+        while (__ballot(need && hi - lo > 1u) != 0ull) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const uint32_t cnt = group_count(ge_mask(mid));
+            if (need && hi - lo > 1u) { if (cnt >= a.prune_n) lo = mid; else hi = mid; }
+        }
+        if (need) mask = ge_mask(lo);
+    }
+    uint32_t mw[4] = {mask.x, mask.y, mask.z, mask.w};
+
+    // pruned (query, batch): one extra record {query, PM_DOC_COUNT, unpruned count, slot}
+    // so the text header can still print the number of documents that passed -t
+    {
+        const unsigned long long bal = __ballot(count_rec);
+        if (bal != 0ull) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            const uint32_t src = (uint32_t)(__ffsll((long long)bal) - 1);
+            unsigned long long basev = 0;
+            if (lane == (int)src) basev = atomicAdd(a.hit_count, (unsigned long long)__popcll(bal));
+            const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, (int)src, 64);
+            const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), (int)src, 64);
+            const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
+            if (count_rec && pos < a.hit_cap) a.hits[pos] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
+        }
     }
 
     // ---- compaction: every round each lane with a pending hit pops one bit;
@@ -487,6 +532,51 @@ hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 262144) blocks = 262144;
     hipLaunchKernelGGL(k_synth, dim3((uint32_t)blocks), dim3(256), 0, st, dst, stride, n_rows, n_docs, kb);
+    return hipGetLastError();
+}
+
+// Ceiling probe: the same access pattern as k_scan (random rows, 16 B per lane,
+// G lanes per row, 8 gathers in flight per lane) with the counting replaced by
+// one XOR per load.  Used only to measure what the memory system delivers for
+// this pattern; not part of the matching path.
+template <int G>
+__global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict__ matrix, uint64_t stride,
+                                                       uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const uint32_t c = lane % G;
+    u32x4 acc = (u32x4)(0u);
+    uint64_t state = splitmix64(group * 0x9E3779B97F4A7C15ULL + 1);
+    const bool active = (uint64_t)c * 16 < stride;
+    for (uint64_t i = 0; i < lookups_per_group; i += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+            const uint64_t r = __umul64hi(state, n_rows);
+            v[k] = (u32x4)(0u);
+            if (active) v[k] = *reinterpret_cast<const u32x4*>(matrix + r * stride + (uint64_t)c * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;   // keeps the loads alive
+}
+hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
+                               uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st) {
+    const uint64_t threads = groups * (uint64_t)g;
+    dim3 grid((uint32_t)((threads + 255) / 256));
+    switch (g) {
+        case 1:  hipLaunchKernelGGL(k_probe_gather<1>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 2:  hipLaunchKernelGGL(k_probe_gather<2>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 4:  hipLaunchKernelGGL(k_probe_gather<4>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 8:  hipLaunchKernelGGL(k_probe_gather<8>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 16: hipLaunchKernelGGL(k_probe_gather<16>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 32: hipLaunchKernelGGL(k_probe_gather<32>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 64: hipLaunchKernelGGL(k_probe_gather<64>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -212,3 +212,40 @@ def test_multi_index_search_slots(pm, oracle):
     assert set(hits["slot"]) <= {40, 41, 42}
     for s, (index, _, _) in enumerate(cases):
         assert pm.format_hits(ixs[s], q, hits, slot=40 + s) == oracle.query_file(index, fasta, 0.7)
+
+
+@pytest.mark.parametrize("n_docs", [13, 100, 300, 664, 1300, 4000, 9001])
+def test_on_device_top_n_with_ties(pm, oracle, n_docs):
+    """search(nb_best_hits=n) keeps exactly the n best documents + ties with the n-th per
+    (query, batch): the rule of scripts/postprocess_cobs.py:31-39, checked against the unpruned hits."""
+    rng = np.random.default_rng(n_docs)
+    queries = [(f"t{i}", rand_seq(rng, 150)) for i in range(16)]
+    plant = []
+    for qi in range(16):
+        docs = rng.choice(n_docs, size=min(n_docs, 40), replace=False)
+        for j, d in enumerate(docs):
+            plant.append((qi, int(d), [1.0, 0.95, 0.9, 0.9, 0.9, 0.85, 0.8, 0.8, 0.75, 0.7][j % 10]))
+    index, fasta, _ = build_case(oracle, rng, n_docs, 4000, queries, plant=plant, density=0.05)
+    ix = pm.Index.load_mem(index)
+    q = pm.Queries(fasta)
+    full = pm.search([ix], q, 0.7).hits()
+    assert len(full) > 16 * min(n_docs, 40) * 0.8
+    for n in (1, 2, 3, 5, 7, 20, 39, 1000):
+        got = pm.search([ix], q, 0.7, nb_best_hits=n).hits()
+        exp, exp_counts = [], {}
+        for qi in range(16):
+            mine = full[full["query"] == qi]            # already ordered score desc, doc asc
+            if len(mine) > n:
+                exp_counts[qi] = len(mine)
+                mine = mine[mine["score"] >= mine["score"][n - 1]]
+            exp.append(mine)
+        exp = np.concatenate(exp)
+        if n_docs > 8192:                                # column-slab batches are pruned at format time
+            assert np.array_equal(got, full)
+        else:
+            meta = got[got["doc"] == pm.PM_DOC_COUNT]
+            assert np.array_equal(got[got["doc"] != pm.PM_DOC_COUNT], exp), n
+            assert {int(m["query"]): int(m["score"]) for m in meta} == exp_counts
+        from phylign_amd import postprocess as P
+        text = pm.format_hits(ix, q, got, slot=0, nb_best_hits=n).decode()
+        assert text == P.filter_text(oracle.query_file(index, fasta, 0.7).decode(), n)

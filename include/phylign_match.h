@@ -36,6 +36,7 @@ extern "C" {
 typedef struct pm_index   pm_index_t;    /* one phylogenetic batch index, resident in HBM */
 typedef struct pm_queries pm_queries_t;  /* a parsed query FASTA, resident in HBM */
 typedef struct pm_result  pm_result_t;   /* hits of one pm_search call */
+typedef struct pm_merge   pm_merge_t;    /* 04_filter state: best matches per query across batches */
 
 /* Row layout policy in HBM (DESIGN.md "Data layout"). */
 #define PM_LAYOUT_AUTO     0  /* line-aligned stride if it fits, else compact */
@@ -111,6 +112,11 @@ int  pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out);
 int  pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signature_size,
                     uint32_t num_hashes, uint32_t term_size, uint64_t seed,
                     int layout, int header_only, pm_index_t** out);
+/* names-only handle from `n_docs` newline-terminated names (rank 0 formats and
+ * merges batches it does not hold) */
+int  pm_index_from_names(const char* names, size_t len, uint32_t n_docs, uint32_t term_size, pm_index_t** out);
+/* releases the HBM matrix, keeps header and names (streaming one batch after another) */
+int  pm_index_drop_matrix(pm_index_t* idx);
 /* sets bit (rows[i], docs[i]) for i<n: planted hits for parity runs */
 int  pm_index_plant(pm_index_t* idx, const uint64_t* rows, const uint32_t* docs, size_t n);
 /* Measurement aid, not part of the matching path: times a pure random-row
@@ -180,6 +186,20 @@ int  pm_format_hits(const pm_index_t* idx, const pm_queries_t* q,
 /* one-shot: what `cobs query -i INDEX -f FASTA -t T` prints */
 int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
                    double threshold, int64_t nb_best_hits, char** text, size_t* len);
+
+/* ---- 04_filter (replaces scripts/filter_queries.py) ---- */
+/* keep = -n of filter_queries.py (config nb_best_hits).  The queries handle must
+ * outlive the merge. */
+int  pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out);
+/* adds the 03_match content of one batch: records of `slot` (count records are
+ * skipped), post-filtered with nb_best_hits like pm_format_hits (>= 0) or taken
+ * as they are (< 0); `batch` is the batch name of the file name
+ * "<batch>____<qfile>.gz" (scripts/filter_queries.py:44), the tie-break after the score. */
+int  pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* idx,
+                  const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits);
+/* ">qname ref1,ref2,...\nseq\n" per query in FASTA order; *text malloc'd, pm_free() */
+int  pm_merge_emit(const pm_merge_t* m, char** text, size_t* len);
+void pm_merge_free(pm_merge_t* m);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,8 @@ SYMBOLS = [
     ("pm_index_load_mem", C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     ("pm_index_load_header_mem", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     ("pm_index_synth", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("pm_index_from_names", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("pm_index_drop_matrix", C.c_int, [_P]),
     ("pm_index_plant", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("pm_index_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("pm_index_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
@@ -80,6 +82,10 @@ SYMBOLS = [
     ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_free", None, [_P]),
     ("pm_format_hits", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pm_merge_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    ("pm_merge_add", C.c_int, [_P, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
+    ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pm_merge_free", None, [_P]),
     ("pm_query_text", C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_double, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
 ]
 
@@ -167,6 +173,19 @@ class Index:
         _chk(load().pm_index_synth(batch_id, n_docs, signature_size, num_hashes, term_size, seed,
                                    layout, int(header_only), C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_names(cls, names, term_size=31):
+        blob = "".join(n + "\n" for n in names).encode()
+        h = _P()
+        _chk(load().pm_index_from_names(blob, len(blob), len(names), term_size, C.byref(h)))
+        return cls(h)
+
+    def names(self):
+        return [self.doc_name(d) for d in range(self.info.n_docs)]
+
+    def drop_matrix(self):
+        _chk(load().pm_index_drop_matrix(self._h))
 
     def plant(self, rows, docs):
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
@@ -302,6 +321,37 @@ def search(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hit
     h = _P()
     _chk(load().pm_search(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
     return Result(h)
+
+
+class Merge:
+    """04_filter state (scripts/filter_queries.py): best `keep` matches (+ties) per query across batches"""
+
+    def __init__(self, queries: Queries, keep=100):
+        h = _P()
+        _chk(load().pm_merge_create(queries._h, keep, C.byref(h)))
+        self._h, self._q = h, queries
+
+    def add(self, batch: str, index: Index, hits, slot=0, nb_best_hits=-1):
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        _chk(load().pm_merge_add(self._h, batch.encode(), index._h, hits.ctypes.data, hits.size, slot, nb_best_hits))
+
+    def emit(self) -> bytes:
+        t, n = _P(), C.c_size_t()
+        _chk(load().pm_merge_emit(self._h, C.byref(t), C.byref(n)))
+        out = C.string_at(t.value, n.value)
+        load().pm_free(t)
+        return out
+
+    def free(self):
+        if self._h:
+            load().pm_merge_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def sort_hits(hits):

@@ -74,12 +74,16 @@ struct pm_index {
 struct pm_queries {
     uint32_t k = 0;
     std::vector<std::string> headers;       // header line without its first byte
+    std::string seqs;                       // packed sequences (host copy, for the 04_filter emit)
+    std::vector<uint64_t> seq_off;          // n_queries + 1
     std::vector<uint32_t> n_terms;
     uint64_t total_terms = 0;
     uint64_t n_slots = 0;                   // padded to 8 per query
     std::vector<QDesc> qd;
     // plane classes: queries ordered by class, ranges per class
     std::vector<uint32_t> qmap;
+    std::vector<uint32_t> blkq;             // 8-slot block -> query
+    bool on_device = false;
     uint32_t class_begin[5] = {0, 0, 0, 0, 0};
     // device
     uint8_t* d_seq = nullptr;
@@ -368,13 +372,13 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
             return fail(PM_EIO, "index stream ended after %llu of %llu matrix bytes",
                         (unsigned long long)(row * rb + (r > 0 ? (uint64_t)r : 0)), (unsigned long long)(S * rb));
         }
-        LCHK(hipMemcpyAsync(dbuf[cur], hbuf[cur], nbytes, hipMemcpyHostToDevice, g_ctx.stream));
-        LCHK(launch_restride(dbuf[cur], rb, ix->d_matrix + row * stride, stride, nrows, g_ctx.stream));
-        LCHK(hipEventRecord(ev[cur], g_ctx.stream));
+        LCHK(hipMemcpyAsync(dbuf[cur], hbuf[cur], nbytes, hipMemcpyHostToDevice, g_ctx.copy_stream));
+        LCHK(launch_restride(dbuf[cur], rb, ix->d_matrix + row * stride, stride, nrows, g_ctx.copy_stream));
+        LCHK(hipEventRecord(ev[cur], g_ctx.copy_stream));
         used[cur] = true;
         row += nrows; cur ^= 1;
     }
-    LCHK(hipStreamSynchronize(g_ctx.stream));
+    LCHK(hipStreamSynchronize(g_ctx.copy_stream));
 #undef LCHK
     cleanup();
     *out = ix;
@@ -490,6 +494,31 @@ extern "C" int pm_index_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
     return PM_OK;
 }
 
+extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_docs, uint32_t term_size, pm_index_t** out) {
+    if ((!names && len) || !out) return fail(PM_EINVAL, "bad argument");
+    pm_index* ix = new pm_index();
+    ix->info.term_size = term_size; ix->info.n_docs = n_docs; ix->info.row_bytes = ((uint64_t)n_docs + 7) / 8;
+    ix->name_off.resize((size_t)n_docs + 1);
+    size_t o = 0;
+    for (uint32_t d = 0; d < n_docs; ++d) {
+        const char* nl = (o < len) ? (const char*)memchr(names + o, '\n', len - o) : nullptr;
+        if (!nl) { delete ix; return fail(PM_EINVAL, "names blob holds fewer than %u newline-terminated names", n_docs); }
+        ix->name_off[d] = ix->names_blob.size();
+        ix->names_blob.append(names + o, (size_t)(nl - (names + o)));
+        ix->names_blob.push_back('\0');
+        o = (size_t)(nl - names) + 1;
+    }
+    ix->name_off[n_docs] = ix->names_blob.size();
+    *out = ix;
+    return PM_OK;
+}
+extern "C" int pm_index_drop_matrix(pm_index_t* ix) {
+    if (!ix) return fail(PM_EINVAL, "bad argument");
+    if (ix->d_matrix) { hipFree(ix->d_matrix); ix->d_matrix = nullptr; }
+    ix->info.has_matrix = 0; ix->info.device_bytes = 0;
+    return PM_OK;
+}
+
 extern "C" int pm_index_info(const pm_index_t* ix, pm_index_info_t* info) {
     if (!ix || !info) return fail(PM_EINVAL, "bad argument");
     *info = ix->info;
@@ -517,12 +546,11 @@ extern "C" void pm_index_free(pm_index_t* ix) {
 // include/phylign_match.h.  The input contract (upper-case ACGT, single line)
 // is produced by Snakefile:314-333.
 extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
-    NEED_DEV();
     if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
     pm_queries* q = new pm_queries();
     q->k = term_size;
-    std::string seqs;            // packed sequences
-    std::vector<uint64_t> seq_off;
+    std::string& seqs = q->seqs;            // packed sequences
+    std::vector<uint64_t>& seq_off = q->seq_off;
     std::string cur_hdr, cur_seq;
     bool have_any = false;
     int rc = PM_OK;
@@ -566,6 +594,7 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
     if (rc != PM_OK) { delete q; return rc; }
 
     const size_t nq = q->headers.size();
+    seq_off.push_back(seqs.size());
     if (nq >= 0xFFFFFFFFull) { delete q; return fail(PM_ERANGE, "too many queries"); }
     q->qd.resize(nq);
     uint64_t blk = 0;
@@ -593,22 +622,9 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
     }
     q->class_begin[4] = (uint32_t)q->qmap.size();
 
-    auto bail = [&](hipError_t e, const char* what) {
-        pm_queries_free(q);
-        return fail(e == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", what, hipGetErrorString(e));
-    };
-    hipError_t e;
-    if (nq) {
-        if ((e = hipMalloc((void**)&q->d_seq, seqs.size() + 64)) != hipSuccess) return bail(e, "hipMalloc seq");
-        if ((e = hipMemset(q->d_seq, 0, seqs.size() + 64)) != hipSuccess) return bail(e, "memset seq");
-        if ((e = hipMalloc((void**)&q->d_qd, nq * sizeof(QDesc))) != hipSuccess) return bail(e, "hipMalloc qd");
-        if ((e = hipMalloc((void**)&q->d_blkq, std::max<size_t>(blkq.size(), 1) * 4)) != hipSuccess) return bail(e, "hipMalloc blkq");
-        if ((e = hipMalloc((void**)&q->d_qmap, nq * 4)) != hipSuccess) return bail(e, "hipMalloc qmap");
-        if ((e = hipMemcpy(q->d_seq, seqs.data(), seqs.size(), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D seq");
-        if ((e = hipMemcpy(q->d_qd, q->qd.data(), nq * sizeof(QDesc), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D qd");
-        if ((e = hipMemcpy(q->d_blkq, blkq.data(), blkq.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D blkq");
-        if ((e = hipMemcpy(q->d_qmap, q->qmap.data(), nq * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "H2D qmap");
-    }
+    q->blkq.swap(blkq);
+    // HBM copies are made on first use by a compute call (upload_queries): parsing, text
+    // formatting and the 04_filter merge are host work and need no GPU
     *out = q;
     return PM_OK;
 }
@@ -635,6 +651,24 @@ extern "C" void pm_queries_free(pm_queries_t* q) {
     delete q;
 }
 
+static int upload_queries(pm_queries* q) {
+    if (q->on_device) return PM_OK;
+    const size_t nq = q->headers.size();
+    if (nq) {
+        HIPCHK(hipMalloc((void**)&q->d_seq, q->seqs.size() + 64));
+        HIPCHK(hipMemset(q->d_seq, 0, q->seqs.size() + 64));
+        HIPCHK(hipMalloc((void**)&q->d_qd, nq * sizeof(QDesc)));
+        HIPCHK(hipMalloc((void**)&q->d_blkq, std::max<size_t>(q->blkq.size(), 1) * 4));
+        HIPCHK(hipMalloc((void**)&q->d_qmap, nq * 4));
+        HIPCHK(hipMemcpy(q->d_seq, q->seqs.data(), q->seqs.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(q->d_qd, q->qd.data(), nq * sizeof(QDesc), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(q->d_blkq, q->blkq.data(), q->blkq.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(q->d_qmap, q->qmap.data(), nq * 4, hipMemcpyHostToDevice));
+    }
+    q->on_device = true;
+    return PM_OK;
+}
+
 // Device hashes for (canonicalize, num_hashes).  The buffer is kept on the query
 // set; the kernel runs once per epoch (pm_search bumps the epoch: one job =
 // hash + scan, nothing is carried over between searches).
@@ -657,6 +691,7 @@ static int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out) 
 extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out) {
     NEED_DEV();
     if (!q || !out || num_hashes == 0) return fail(PM_EINVAL, "bad argument");
+    { int urc = upload_queries(q); if (urc) return urc; }
     q->epoch++;           // force a fresh kernel run
     uint64_t* d_h = nullptr;
     int rc = ensure_hashes(q, canonicalize ? 1 : 0, num_hashes, &d_h);
@@ -714,6 +749,7 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     }
     const size_t nq = q->headers.size();
     hipStream_t st = g_ctx.stream;
+    { int urc = upload_queries(q); if (urc) return urc; }
 
     // ---- launch plan: one scan launch per (lanes-per-row class, canonicalize,
     // num_hashes) x counter-width class covers every batch of that class;
@@ -1028,3 +1064,124 @@ extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len
     pm_queries_free(q);
     return rc;
 }
+
+// --------------------------------------------------------- 04_filter merge
+// Native form of the reference's consumer (scripts/filter_queries.py:107-206):
+// for every query keep the globally best `keep` matches across batches plus the
+// ones tied with the last of them, ordered by (-kmers, batch, ref), and emit
+// ">qname ref1,ref2,...\nseq".  What is merged per batch is what the 03_match
+// file of that batch holds, i.e. the hit list after the per-batch post-filter
+// (scripts/postprocess_cobs.py:21-39 with -n nb_best_hits).
+struct MergeItem { uint32_t kmers; uint32_t batch; std::string ref; };
+struct pm_merge {
+    const pm_queries* q = nullptr;
+    uint32_t keep = 0;
+    std::vector<std::string> batches;
+    std::map<std::string, uint32_t> by_name;        // query name (first word) -> record index
+    std::vector<std::string> qnames;
+    std::vector<std::vector<MergeItem>> items;
+    std::vector<uint32_t> floor_;
+};
+
+extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
+    if (!q || !out) return fail(PM_EINVAL, "bad argument");
+    pm_merge* m = new pm_merge();
+    m->q = q; m->keep = keep;
+    const size_t nq = q->headers.size();
+    m->items.resize(nq); m->floor_.assign(nq, 0); m->qnames.resize(nq);
+    for (size_t i = 0; i < nq; ++i) {
+        // readfq name: the header up to its first space (scripts/filter_queries.py:80)
+        const std::string& h = q->headers[i];
+        m->qnames[i] = h.substr(0, h.find(' '));
+        m->by_name[m->qnames[i]] = (uint32_t)i;        // duplicates: the last record wins, as in a dict
+    }
+    *out = m;
+    return PM_OK;
+}
+
+extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* ix,
+                            const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
+    if (!m || !batch || !ix || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
+    const size_t nq = m->q->headers.size();
+    std::vector<pm_hit_t> mine;
+    for (uint64_t i = 0; i < n_hits; ++i)
+        if (hits[i].slot == slot && hits[i].doc != PM_DOC_COUNT) {
+            if (hits[i].query >= nq || hits[i].doc >= ix->info.n_docs)
+                return fail(PM_EINVAL, "hit record out of range for batch %s", batch);
+            mine.push_back(hits[i]);
+        }
+    order_hits(mine.data(), mine.size());
+    const uint32_t bid = (uint32_t)m->batches.size();
+    m->batches.push_back(batch);
+    size_t p = 0;
+    while (p < mine.size()) {
+        size_t e = p;
+        const uint32_t qi = mine[p].query;
+        while (e < mine.size() && mine[e].query == qi) ++e;
+        // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
+        // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
+        const std::string& h = m->q->headers[qi];
+        std::string key = h.substr(0, h.find('\t'));
+        key = key.substr(0, key.find(' '));
+        auto it = m->by_name.find(key);
+        if (it == m->by_name.end()) return fail(PM_EINVAL, "query '%s' of batch %s is not in the query file", key.c_str(), batch);
+        const uint32_t target = it->second;
+        std::vector<MergeItem>& v = m->items[target];
+        uint32_t nth = 0;
+        for (size_t i = p; i < e; ++i) {
+            if (nb_best >= 0) {                          // per-batch post-filter, same rule as pm_format_hits
+                const int64_t rank = (int64_t)(i - p) + 1;
+                if (rank == nb_best) nth = mine[i].score;
+                if (rank > nb_best && mine[i].score != nth) continue;
+            }
+            const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
+            const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
+            const char* us = (const char*)memchr(nm, '_', nl);
+            if (!us || memchr(us + 1, '_', nl - (size_t)(us + 1 - nm)))
+                return fail(PM_EINVAL, "document name '%.*s' must hold exactly one '_' (scripts/filter_queries.py:64)", (int)nl, nm);
+            if (mine[i].score >= m->floor_[target])
+                v.push_back({mine[i].score, bid, std::string(us + 1, nl - (size_t)(us + 1 - nm))});
+        }
+        std::sort(v.begin(), v.end(), [&](const MergeItem& a, const MergeItem& b) {
+            if (a.kmers != b.kmers) return a.kmers > b.kmers;
+            if (a.batch != b.batch) return m->batches[a.batch] < m->batches[b.batch];
+            return a.ref < b.ref;
+        });
+        if (v.size() > m->keep) {
+            if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
+            size_t cut = m->keep;
+            m->floor_[target] = v[cut - 1].kmers;
+            while (cut < v.size() && v[cut].kmers == m->floor_[target]) ++cut;
+            v.resize(cut);
+        }
+        p = e;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
+    if (!m || !text || !len) return fail(PM_EINVAL, "bad argument");
+    std::string out;
+    const pm_queries* q = m->q;
+    // dict semantics of the consumer: one record per distinct name, at the position of its
+    // first occurrence, with the sequence of its last occurrence
+    std::vector<char> seen(q->headers.size(), 0);
+    for (size_t i = 0; i < q->headers.size(); ++i) {
+        const uint32_t rec = m->by_name.at(m->qnames[i]);
+        if (seen[rec]) continue;
+        seen[rec] = 1;
+        out.push_back('>'); out += m->qnames[i]; out.push_back(' ');
+        const std::vector<MergeItem>& v = m->items[rec];
+        for (size_t k = 0; k < v.size(); ++k) { if (k) out.push_back(','); out += v[k].ref; }
+        out.push_back('\n');
+        out.append(q->seqs, (size_t)q->seq_off[rec], (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]));
+        out.push_back('\n');
+    }
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
+    *text = buf; *len = out.size();
+    return PM_OK;
+}
+
+extern "C" void pm_merge_free(pm_merge_t* m) { delete m; }

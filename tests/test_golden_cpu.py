@@ -222,8 +222,12 @@ def test_product_fails_loudly_without_gpu():
     with pytest.raises(_lib.PMError) as e:
         _lib.init(0)
     assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    q = _lib.Queries(b">q\nACGT\n", term_size=3)       # parsing is host work ...
     with pytest.raises(_lib.PMError) as e:
-        _lib.Queries(b">q\nACGT\n", term_size=3)
+        q.hash_terms(1, 1)                              # ... every compute entry point needs the GPU
+    assert e.value.code == -2
+    with pytest.raises(_lib.PMError) as e:
+        _lib.Index.synth(1, 10, 10)
     assert e.value.code == -2
     # the one host-only rule of the path is callable without a device and equals the oracle's
     assert _lib.threshold_terms(0.7, 121) == 85
@@ -244,3 +248,61 @@ def test_product_never_imports_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
             src = open(path).read()
             assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or path.endswith("build.py"), path
+
+
+# ------------------- native (C++) post-filter and 04_filter merge, host-only paths
+def _structured(text):
+    """COBS text -> (fasta bytes, names, hit records) with doc ids in order of first appearance"""
+    from phylign_amd import _lib as pm
+    names, recs, fasta, qi = {}, [], [], -1
+    for line in text.splitlines():
+        if line.startswith("*"):
+            qi += 1
+            fasta.append(">" + line[1:].rsplit("\t", 1)[0] + "\nACGTACGTACGTACGTACGTACGTACGTACGTA\n")
+        else:
+            name, score = line.rsplit("\t", 1)
+            d = names.setdefault(name, len(names))
+            recs.append((qi, d, int(score), 0))
+    return "".join(fasta).encode(), list(names), np.array(recs, dtype=pm.HIT_DTYPE)
+
+
+@pytest.mark.parametrize("case", ["survey_a4", "zero_hits", "ties_small", "random_mid", "ties_large", "underscores"])
+def test_native_postfilter_matches_reference_fixtures(case):
+    """pm_format_hits(nb_best_hits=n) against outputs of the reference's postprocess_cobs.py"""
+    from phylign_amd import _lib as pm
+    base = os.path.join(GOLD, "postprocess", case)
+    text = open(base + ".in").read()
+    fasta, names, hits = _structured(text)
+    q = pm.Queries(fasta, term_size=31)
+    ix = pm.Index.from_names(names)
+    assert pm.format_hits(ix, q, hits, slot=0, nb_best_hits=-1).decode() == text      # plain cobs text round-trips
+    for n in (0, 1, 2, 3, 100):
+        if os.path.exists(f"{base}.n{n}.out"):
+            assert pm.format_hits(ix, q, hits, slot=0, nb_best_hits=n).decode() == open(f"{base}.n{n}.out").read()
+        else:
+            with pytest.raises(pm.PMError):
+                pm.format_hits(ix, q, hits, slot=0, nb_best_hits=n)
+
+
+@pytest.mark.parametrize("keep", [1, 2, 5, 100])
+def test_native_merge_matches_reference_filter_fixture(keep):
+    """pm_merge_* against the output of the reference's filter_queries.py"""
+    import gzip
+    from phylign_amd import _lib as pm
+    d = os.path.join(GOLD, "filter")
+    q = pm.Queries(open(os.path.join(d, "queries.fa"), "rb").read(), term_size=31)
+    order = {}
+    for i, line in enumerate(l for l in open(os.path.join(d, "queries.fa")) if l.startswith(">")):
+        order[line[1:].split()[0]] = i
+    m = pm.Merge(q, keep)
+    for b in ("aaa_bbb__01", "ccc_ddd__01", "ccc_ddd__02"):
+        names, recs, qi = {}, [], None
+        for line in gzip.open(os.path.join(d, f"{b}____q.gz"), "rt"):
+            if line.startswith("*"):
+                qi = order[line[1:].split("\t")[0].split(" ")[0]]
+            else:
+                name, score = line.split()
+                recs.append((qi, names.setdefault(name, len(names)), int(score), 7))
+        ix = pm.Index.from_names(list(names) or ["x_y"])
+        m.add(b, ix, np.array(recs, dtype=pm.HIT_DTYPE), slot=7, nb_best_hits=-1)
+    assert m.emit().decode() == open(os.path.join(d, f"expected.n{keep}.fa")).read()

@@ -115,3 +115,69 @@ def test_match_to_filter_dropin(pm, oracle, tmp_path):
     recs = out.getvalue().strip().split("\n")
     assert len(recs) == 24 and recs[0].startswith(">r0 ")
     assert all(len(recs[i].split(" ")[1].split(",")) >= 3 for i in range(0, 24, 2))
+
+
+def _stage_fixture(oracle, tmp_path, n_batches=5):
+    """a small cobs/ directory with xz indexes, a batches file, the sizes table and a query FASTA"""
+    rng = np.random.default_rng(77)
+    queries = [(f"q{i} c", rand_seq(rng, 150)) for i in range(20)]
+    cobs = tmp_path / "cobs"
+    cobs.mkdir()
+    shapes = [(195, 5000), (176, 9000), (664, 6000), (4000, 3000), (30, 4000)][:n_batches]
+    names, indexes = [], {}
+    with open(tmp_path / "sizes.txt", "w") as sz:
+        for b, (n_docs, S) in enumerate(shapes):
+            batch = f"genus_species{b}__01"
+            plant = [(qi, (qi * 11 + j * 3) % n_docs, fr) for qi in range(20)
+                     for j, fr in enumerate((1.0, 0.95, 0.9, 0.9, 0.8, 0.8, 0.8, 0.7))]
+            index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant)
+            (cobs / f"{batch}.cobs_classic.xz").write_bytes(lzma.compress(bytes(index), preset=1))
+            sz.write(f"cobs/{batch}.cobs_classic.xz  {len(index)}  1610678320\n")
+            names.append(batch)
+            indexes[batch] = index
+    (tmp_path / "batches.txt").write_text("\n".join(reversed(names)) + "\n")
+    (tmp_path / "Q.fa").write_bytes(fasta)
+    return names, indexes, fasta
+
+
+def _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, n):
+    from phylign_amd import filter_queries as F
+    from phylign_amd import postprocess as P
+    files = []
+    for b in names:
+        exp = P.filter_text(oracle.query_file(indexes[b], fasta, 0.7).decode(), n)
+        fn = tmp_path / "03_match" / f"{b}____Q.gz"
+        assert gzip.open(fn, "rt").read() == exp, b
+        files.append(str(fn))
+    out = io.StringIO()
+    F.filter_files(str(tmp_path / "Q.fa"), files, n, out)          # golden-pinned mirror of filter_queries.py
+    assert (tmp_path / "04_filter" / "Q.fa").read_text() == out.getvalue()
+    assert not list((tmp_path / "03_match").glob("*.tmp"))
+
+
+@pytest.mark.parametrize("n", [3, 100])
+def test_match_stage_end_to_end_single_rank(pm, oracle, tmp_path, n):
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+                        "--cobs-dir", str(tmp_path / "cobs"), "--sizes", str(tmp_path / "sizes.txt"),
+                        "--queries", str(tmp_path / "Q.fa"), "--out-dir", str(tmp_path / "03_match"),
+                        "--nb-best-hits", str(n), "--filter-out", str(tmp_path / "04_filter" / "Q.fa"), "--loaders", "3"],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, n)
+
+
+def test_match_stage_two_ranks_gather(pm, oracle, tmp_path):
+    """the N>1 code path (static sharding, gather of hit records + names to rank 0) with two
+    ranks sharing the one GPU over gloo; on a multi-GPU node the same code runs over RCCL"""
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT, PHYLIGN_DIST_BACKEND="gloo", PHYLIGN_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", "-m", "phylign_amd.match_stage",
+                        "--batches", str(tmp_path / "batches.txt"), "--cobs-dir", str(tmp_path / "cobs"),
+                        "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"),
+                        "--out-dir", str(tmp_path / "03_match"), "--nb-best-hits", "3",
+                        "--filter-out", str(tmp_path / "04_filter" / "Q.fa")], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)

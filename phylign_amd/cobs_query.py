@@ -8,12 +8,16 @@ Accepts the argv the reference passes to the external binary
 and prints the same result text on stdout.  INDEX may be a regular file or a
 pipe such as /dev/fd/63.  `--load-complete` and `-T` are accepted and ignored
 (the index is always fully resident in HBM; results never depended on the
-thread count).  Extension: `--nb-best-hits N` fuses `postprocess_cobs.py -n N`
-(Snakefile:425 / :467) into the same process; `--device D` picks the GPU.
+thread count).  Extensions: `--nb-best-hits N` fuses `postprocess_cobs.py -n N`
+(Snakefile:425 / :467) into the same process; `--device D` picks the GPU;
+`--server SOCK` (or PHYLIGN_MATCH_SERVER) sends the job to a resident-index
+server (phylign_amd/server.py) -- then INDEX must be a path the server can open
+(the .xz itself is fine, the server decodes it once and keeps it in HBM).
 Any failure exits non-zero with the reason on stderr (Snakefile:142 runs rules
 under `set -euo pipefail`; scripts/benchmark.py:56-61 re-raises).
 """
 import argparse
+import os
 import sys
 
 
@@ -32,6 +36,8 @@ def build_parser():
     q.add_argument("--nb-best-hits", type=int, default=None,
                    help="fuse scripts/postprocess_cobs.py -n N into the output")
     q.add_argument("--device", type=int, default=0, help="GPU ordinal")
+    q.add_argument("--server", default=os.environ.get("PHYLIGN_MATCH_SERVER"),
+                   help="unix socket of a resident-index server")
     return ap
 
 
@@ -43,6 +49,18 @@ def run_query(args, out=None):
     if args.limit:
         raise SystemExit("error: -l/--limit is not supported; Phylign never passes it (use --nb-best-hits)")
     size_hint = args.index_sizes[0] if args.index_sizes else 0
+    if args.server:
+        from .server import request
+        with open(args.query_file, "rb") as f:
+            fasta = f.read()
+        head, body = request(args.server, {"op": "query", "index": os.path.abspath(args.index[0]), "index_size": size_hint,
+                                           "fasta_len": len(fasta), "threshold": args.threshold,
+                                           "nb_best_hits": args.nb_best_hits}, fasta)
+        if not head.get("ok"):
+            raise RuntimeError(head.get("error", "server error"))
+        out.write(body)
+        out.flush()
+        return
     pm.init(args.device)
     ix = pm.Index.load_file(args.index[0], size_hint=size_hint)
     with open(args.query_file, "rb") as f:

@@ -15,7 +15,14 @@ if [[ $# -ne 5 ]]; then
 fi
 thres="$1"; nthreads="$2"; index_xz="$3"; index_bytes="$4"; fasta="$5"
 
-PYTHONPATH="${here}/..${PYTHONPATH:+:$PYTHONPATH}" exec python3 -m phylign_amd.cobs_query query --load-complete \
+export PYTHONPATH="${here}/..${PYTHONPATH:+:$PYTHONPATH}"
+if [[ -n "${PHYLIGN_MATCH_SERVER:-}" ]]; then
+	# resident-index server: it decodes the .xz once and keeps the matrix in HBM
+	exec python3 -m phylign_amd.cobs_query query --load-complete -t "${thres}" -T "${nthreads}" \
+		-i "${index_xz}" --index-sizes "${index_bytes}" -f "${fasta}" --server "${PHYLIGN_MATCH_SERVER}" \
+		${PHYLIGN_NB_BEST_HITS:+--nb-best-hits "${PHYLIGN_NB_BEST_HITS}"}
+fi
+exec python3 -m phylign_amd.cobs_query query --load-complete \
 	-t "${thres}" \
 	-T "${nthreads}" \
 	-i <(xzcat --no-sparse --ignore-check "${index_xz}") \

@@ -181,3 +181,48 @@ def test_match_stage_two_ranks_gather(pm, oracle, tmp_path):
                         "--filter-out", str(tmp_path / "04_filter" / "Q.fa")], capture_output=True, env=env)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+
+
+def test_resident_index_server(pm, oracle, tmp_path):
+    """persistent residency: the second job on the same index skips decode + upload"""
+    import time
+    from phylign_amd.server import request
+    index, fasta, _ = _case(oracle, seed=41, n_docs=664, S=400000)
+    xz = tmp_path / "big__01.cobs_classic.xz"
+    xz.write_bytes(lzma.compress(bytes(index), preset=0))
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(fasta)
+    sock = str(tmp_path / "pm.sock")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    srv = subprocess.Popen([sys.executable, "-m", "phylign_amd.server", "--socket", sock], env=env, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.1)
+        assert os.path.exists(sock), "server did not come up"
+        exp = oracle.query_file(index, fasta, 0.7)
+        script = os.path.join(ROOT, "scripts", "run_cobs_streaming.sh")
+        cenv = dict(env, PHYLIGN_MATCH_SERVER=sock)
+        outs = []
+        for _ in range(2):
+            r = subprocess.run([script, "0.7", "1", str(xz), str(len(index)), str(fa)], capture_output=True, env=cenv)
+            assert r.returncode == 0, r.stderr.decode()
+            outs.append(r.stdout)
+        assert outs[0] == exp and outs[1] == exp
+        h1, b1 = request(sock, {"op": "query", "index": str(xz), "index_size": len(index), "fasta_len": len(fasta),
+                                "threshold": 0.7, "nb_best_hits": 2}, fasta)
+        from phylign_amd import postprocess as P
+        assert h1["ok"] and h1["cached"] and b1.decode() == P.filter_text(exp.decode(), 2)
+        st, _ = request(sock, {"op": "stats"})
+        assert st["loads"] == 1 and st["hits"] == 2 and st["resident"] == 1
+        bad, _ = request(sock, {"op": "query", "index": str(tmp_path / "missing.xz"), "fasta_len": 0})
+        assert not bad["ok"]
+        r = subprocess.run([script, "0.7", "1", str(tmp_path / "missing.xz"), "1", str(fa)], capture_output=True, env=cenv)
+        assert r.returncode != 0 and r.stdout == b""
+    finally:
+        try:
+            request(sock, {"op": "shutdown"})
+        except Exception:
+            srv.kill()
+        srv.wait(timeout=30)

@@ -240,7 +240,6 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     in.header_layout = (uint32_t)h.layout;
     in.has_matrix = 0; in.stride = 0; in.device_bytes = 0;
     if (!want_matrix) return PM_OK;
-    if (h.sig > 0xFFFFFFFFull) return fail(PM_ERANGE, "signature_size %llu >= 2^32 rows is not supported by this build", (unsigned long long)h.sig);
     if (in.row_bytes == 0) return fail(PM_EFORMAT, "index holds no documents");
     uint64_t sc = stride_compact(in.row_bytes), sa = stride_aligned(in.row_bytes);
     uint64_t stride = sc;

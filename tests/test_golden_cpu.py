@@ -306,3 +306,22 @@ def test_native_merge_matches_reference_filter_fixture(keep):
         ix = pm.Index.from_names(list(names) or ["x_y"])
         m.add(b, ix, np.array(recs, dtype=pm.HIT_DTYPE), slot=7, nb_best_hits=-1)
     assert m.emit().decode() == open(os.path.join(d, f"expected.n{keep}.fa")).read()
+
+
+# ------------------------------------------------------ fix_query mirror (f4)
+def test_fix_query_rules_and_awk_fixed_point(tmp_path):
+    from phylign_amd import fix_query as FQ
+    src = (b"@r1 some comment\nacgtNNryACGT\nACGT\n+\nII@IIIIIIIIIIIII\n"
+           b">r2 x y\nacg\ntnn\n\n>r3\n@r4\nGATTACA\n+r4\n@@@@@@@\n")
+    out = io.BytesIO()
+    FQ.fix_stream(io.BytesIO(src), out)
+    got = out.getvalue()
+    assert got == b">r1\nACGTAAAAACGTACGT\n>r2\nACGTAA\n>r3\n\n>r4\nGATTACA\n"
+    # the awk half of the rule (Snakefile:330-332) leaves the mirror's output unchanged
+    p = tmp_path / "x.fa"
+    p.write_bytes(got)
+    r = subprocess.run(["awk", '{if(NR%2==1){print $0;}else{gsub(/[^ACGT]/, "A"); print;}}', str(p)], capture_output=True)
+    assert r.returncode == 0 and r.stdout == got
+    merged = open(os.path.join(GOLD, "reads", "reads_1___reads_2___reads_3___reads_4.fa"), "rb").read()
+    assert merged.count(b">") == 40 and merged.startswith(b">1A\nTTTGAAATCC") and b">4J\n" in merged
+    assert set(merged.replace(b">", b"").replace(b"\n", b"")) <= set(b"ACGT0123456789ABCDEFGHIJ")

@@ -125,3 +125,49 @@ def test_config3_full_size_sampled_parity_and_invariants(pm, oracle):
             got.append(pm.search([ix], q, 0.7, slot_base=pos).hits())
             ix.free()
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], hits[hits["slot"] == pos])
+
+
+def test_config1_bundled_reads_on_batches_small_shapes(pm, oracle, tmp_path):
+    """BASELINE configs[0] shape: the reference's 40 bundled reads (data/reads_{1..4}) against the three
+    batches of data/batches_small.txt at their real shapes (195/176/664 documents, 6.5M-16.5M rows),
+    synthetic signatures with the reads planted; every read x batch compared with the oracle, then the
+    `make test` setting nb_best_hits=1 (Makefile:44) through the fused post-filter."""
+    import os
+    from phylign_amd import postprocess as P
+    fasta = open(os.path.join(os.path.dirname(__file__), "golden", "reads", "reads_1___reads_2___reads_3___reads_4.fa"), "rb").read()
+    recs = fasta.decode().split("\n")
+    names, seqs = [r[1:] for r in recs[0::2] if r], [r.encode() for r in recs[1::2] if r]
+    assert len(names) == 40 and names[0] == "1A" and names[-1] == "4J"
+    shapes = W.select("small")
+    assert [(s.n_docs, s.row_bytes) for s in shapes] == [(195, 25), (176, 22), (664, 83)]
+    q = pm.Queries(fasta)
+    rng = np.random.default_rng(12)
+    for pos, s in enumerate(shapes):
+        ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, seed=SEED)
+        rows, docs = [], []
+        for qi in range(pos, 40, 3):                     # each read is "from" one of the three species
+            hs = oracle.create_hashes(seqs[qi], 31, 1, 1)
+            for d, frac in zip(rng.choice(s.n_docs, size=12, replace=False), [1.0] * 5 + [0.9, 0.9, 0.8, 0.75, 0.7, 0.69, 0.5]):
+                m = int(np.ceil(frac * len(hs)))
+                rows += [int(h) % s.signature_size for h in hs[:m]]
+                docs += [int(d)] * m
+        ix.plant(rows, docs)
+        ov = _overlay(np.array(rows), np.array(docs))
+        hits = pm.search([ix], q, 0.7, slot_base=pos).hits()
+
+        class _S:                                        # rows of varying length: per-read sequences
+            def __getitem__(self, i):
+                return np.frombuffer(seqs[i], dtype=np.uint8)
+        exp = _expected_hits(oracle, s, _S(), list(range(40)), ov, 0.7)
+        assert [(int(x["query"]), int(x["doc"]), int(x["score"])) for x in hits] == exp
+        assert len(exp) >= 13 * 9
+        # text with nb_best_hits = 1, built from the oracle's expectation through the post-filter mirror
+        name_of = [ix.doc_name(d) for d in range(s.n_docs)]
+        lines = []
+        for qi in range(40):
+            mine = [(d, v) for (qq, d, v) in exp if qq == qi]
+            lines.append(f"*{names[qi]}\t{len(mine)}\n" + "".join(f"{name_of[d]}\t{v}\n" for d, v in mine))
+        want = P.filter_text("".join(lines), 1)
+        got = pm.search([ix], q, 0.7, slot_base=pos, nb_best_hits=1)
+        assert pm.format_hits(ix, q, got.hits(), slot=pos, nb_best_hits=1).decode() == want
+        ix.free()

@@ -54,6 +54,9 @@ typedef struct {
     uint64_t device_bytes;     /* HBM held by the matrix */
     uint32_t header_layout;    /* which header field order validated (0/1) */
     uint32_t has_matrix;       /* 0 for header-only handles */
+    uint32_t n_parts;          /* 0 for a classic index; sub-indexes of a compact index */
+    uint32_t reserved;
+    uint64_t page_size;        /* compact: bytes per sub-index row (row_bytes reports it too) */
 } pm_index_info_t;
 
 /* One hit record, 16 bytes; identical in HBM, on the wire (RCCL) and on host.
@@ -101,7 +104,10 @@ uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);
 
 /* ---- index (replaces `cobs query -i`, --load-complete, --index-sizes) --- */
 /* path may be a regular file or a pipe (/dev/fd/N as produced by
- * run_cobs_streaming.sh:27); size_hint = --index-sizes value or 0. */
+ * run_cobs_streaming.sh:27); size_hint = --index-sizes value or 0.  Both
+ * "CLASSIC_INDEX" files (what Phylign ships, Snakefile:48) and "COMPACT_INDEX"
+ * files are accepted; a compact index is held as one matrix per page column
+ * and searched like several classic indexes that share one slot. */
 int  pm_index_load_file(const char* path, uint64_t size_hint, int layout, pm_index_t** out);
 int  pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out);
 int  pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out);

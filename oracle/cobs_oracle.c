@@ -230,6 +230,90 @@ size_t orc_select(const uint32_t* scores, uint32_t n_docs, uint64_t num_terms,
     return n;
 }
 
+/* ---------------------------------------------------------- compact index */
+/* upstream cobs/file/compact_index_header.cpp serialize():
+ *   "COBS:" "COMPACT_INDEX" u32 version=1 | u32 term_size, u8 canonicalize,
+ *   u32 n_parameters, u32 n_file_names, u64 page_size |
+ *   n_parameters x {u64 signature_size, u64 num_hashes} | names '\n'... |
+ *   zero padding so that the closing "COMPACT_INDEX" ends on a page boundary |
+ *   "COMPACT_INDEX" | sub-index 0 (signature_size_0 x page_size bytes) | sub-index 1 ...
+ * Sub-index p holds documents [p*page_size*8, (p+1)*page_size*8).  Query
+ * (upstream compact_index/mmap_search_file.cpp): row of sub-index p = hash %
+ * signature_size_p; hash functions 0..num_hashes_p-1. */
+static const char MAGICC[] = "COMPACT_INDEX";
+int orc_compact_parse(const uint8_t* buf, size_t len, orc_compact_t* c) {
+    if (len < 18 + 4 + 4 + 1 + 4 + 4 + 8 || memcmp(buf, MAGIC0, 5) || memcmp(buf + 5, MAGICC, 13)) return -1;
+    size_t o = 18; uint32_t ver;
+    memcpy(&ver, buf + o, 4); o += 4;
+    memcpy(&c->term_size, buf + o, 4); o += 4;
+    c->canonicalize = buf[o]; o += 1;
+    memcpy(&c->n_parts, buf + o, 4); o += 4;
+    memcpy(&c->n_docs, buf + o, 4); o += 4;
+    memcpy(&c->page_size, buf + o, 8); o += 8;
+    if (ver != 1 || c->term_size == 0 || c->canonicalize > 1 || c->page_size == 0 || c->n_parts == 0) return -1;
+    if ((uint64_t)c->n_parts * c->page_size * 8 < c->n_docs) return -1;
+    c->params_off = o;
+    if (o + (size_t)c->n_parts * 16 > len) return -1;
+    o += (size_t)c->n_parts * 16;
+    c->names_off = o;
+    for (uint32_t d = 0; d < c->n_docs; d++) {
+        const uint8_t* nl = (o < len) ? memchr(buf + o, '\n', len - o) : NULL;
+        if (!nl) return -1;
+        o = (size_t)(nl - buf) + 1;
+    }
+    o += (size_t)((c->page_size - ((o + 13) % c->page_size)) % c->page_size);
+    if (o + 13 > len || memcmp(buf + o, MAGICC, 13) != 0) return -1;
+    c->data_off = o + 13;
+    uint64_t need = 0;
+    for (uint32_t p = 0; p < c->n_parts; p++) {
+        uint64_t sig, nh; memcpy(&sig, buf + c->params_off + 16 * p, 8); memcpy(&nh, buf + c->params_off + 16 * p + 8, 8);
+        if (sig == 0 || nh == 0) return -1;
+        need += sig * c->page_size;
+    }
+    if (need > len - c->data_off) return -1;
+    return 0;
+}
+uint8_t* orc_compact_alloc(uint32_t term_size, uint8_t canon, uint64_t page_size, uint32_t n_parts,
+                           const uint64_t* sig_sizes, const uint64_t* num_hashes, uint32_t n_docs,
+                           const char* const* names, size_t* total_len, size_t* data_off) {
+    size_t hl = 18 + 4 + 4 + 1 + 4 + 4 + 8 + (size_t)n_parts * 16;
+    for (uint32_t d = 0; d < n_docs; d++) hl += strlen(names[d]) + 1;
+    hl += (size_t)((page_size - ((hl + 13) % page_size)) % page_size) + 13;
+    size_t tot = hl;
+    for (uint32_t p = 0; p < n_parts; p++) tot += (size_t)(sig_sizes[p] * page_size);
+    uint8_t* b = (uint8_t*)calloc(tot, 1);
+    if (!b) return NULL;
+    size_t o = 0; uint32_t ver = 1;
+    memcpy(b + o, MAGIC0, 5); o += 5; memcpy(b + o, MAGICC, 13); o += 13;
+    memcpy(b + o, &ver, 4); o += 4; memcpy(b + o, &term_size, 4); o += 4; b[o++] = canon;
+    memcpy(b + o, &n_parts, 4); o += 4; memcpy(b + o, &n_docs, 4); o += 4; memcpy(b + o, &page_size, 8); o += 8;
+    for (uint32_t p = 0; p < n_parts; p++) { memcpy(b + o, &sig_sizes[p], 8); memcpy(b + o + 8, &num_hashes[p], 8); o += 16; }
+    for (uint32_t d = 0; d < n_docs; d++) { size_t l = strlen(names[d]); memcpy(b + o, names[d], l); o += l; b[o++] = '\n'; }
+    o = hl - 13;
+    memcpy(b + o, MAGICC, 13);
+    *total_len = tot; *data_off = hl;
+    return b;
+}
+int orc_scores_compact(const uint8_t* index, const orc_compact_t* c, const char* seq, size_t len, uint32_t* scores) {
+    if (len < c->term_size) return -1;
+    memset(scores, 0, (size_t)c->n_docs * 4);
+    const uint8_t* part = index + c->data_off;
+    for (uint32_t p = 0; p < c->n_parts; p++) {
+        orc_header_t h; memset(&h, 0, sizeof h);
+        memcpy(&h.signature_size, index + c->params_off + 16 * p, 8);
+        memcpy(&h.num_hashes, index + c->params_off + 16 * p + 8, 8);
+        h.term_size = c->term_size; h.canonicalize = c->canonicalize;
+        uint64_t first = (uint64_t)p * c->page_size * 8;
+        if (first >= c->n_docs) break;
+        uint64_t nd = c->n_docs - first; if (nd > c->page_size * 8) nd = c->page_size * 8;
+        h.n_docs = (uint32_t)nd; h.row_bytes = (nd + 7) / 8;
+        int rc = orc_scores(part, c->page_size, &h, seq, len, scores + first);
+        if (rc) return rc;
+        part += h.signature_size * c->page_size;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------- cobs query -f    */
 /* upstream src/main.cpp process_query (file branch): std::getline loop; empty
  * lines skipped; a line starting with '>' or ';' flushes the pending record
@@ -242,17 +326,19 @@ static void sb_put(sbuf* s, const char* d, size_t l) {
     if (s->n + l + 1 > s->cap) { s->cap = (s->n + l + 1) * 2; s->p = (char*)realloc(s->p, s->cap); }
     memcpy(s->p + s->n, d, l); s->n += l; s->p[s->n] = 0;
 }
-static int flush_record(sbuf* out, const uint8_t* index, const orc_header_t* h,
+typedef struct { const orc_header_t* h; const orc_compact_t* c; uint32_t term_size, n_docs; } any_index;
+static int flush_record(sbuf* out, const uint8_t* index, const any_index* ai,
                         const char* const* names, const size_t* name_len,
                         const char* hdr, size_t hdr_len, const char* seq, size_t seq_len,
                         double threshold, size_t num_results, char* err, size_t errcap) {
     if (seq_len == 0) return 0;
-    if (seq_len < h->term_size) { snprintf(err, errcap, "query too short, needs at least %u characters", h->term_size); return -1; }
-    uint32_t* sc = (uint32_t*)malloc(((size_t)h->n_docs + 1) * 4);
-    int rc = orc_scores(index + h->data_off, h->row_bytes, h, seq, seq_len, sc);
+    if (seq_len < ai->term_size) { snprintf(err, errcap, "query too short, needs at least %u characters", ai->term_size); return -1; }
+    uint32_t* sc = (uint32_t*)malloc(((size_t)ai->n_docs + 1) * 4);
+    int rc = ai->h ? orc_scores(index + ai->h->data_off, ai->h->row_bytes, ai->h, seq, seq_len, sc)
+                   : orc_scores_compact(index, ai->c, seq, seq_len, sc);
     if (rc) { free(sc); snprintf(err, errcap, "invalid base in query (only ACGT accepted)"); return -1; }
-    orc_hit_t* hits = (orc_hit_t*)malloc(((size_t)h->n_docs + 1) * sizeof(orc_hit_t));
-    size_t n = orc_select(sc, h->n_docs, seq_len - h->term_size + 1, threshold, num_results, hits);
+    orc_hit_t* hits = (orc_hit_t*)malloc(((size_t)ai->n_docs + 1) * sizeof(orc_hit_t));
+    size_t n = orc_select(sc, ai->n_docs, seq_len - ai->term_size + 1, threshold, num_results, hits);
     char num[64];
     sb_put(out, hdr, hdr_len);
     sb_put(out, num, (size_t)snprintf(num, sizeof num, "\t%zu\n", n));
@@ -265,11 +351,16 @@ static int flush_record(sbuf* out, const uint8_t* index, const orc_header_t* h,
 }
 char* orc_query_file(const uint8_t* index, size_t index_len, const char* fasta, size_t fasta_len,
                      double threshold, size_t num_results, size_t* out_len, char* err, size_t errcap) {
-    orc_header_t h;
-    if (orc_header_parse(index, index_len, &h)) { snprintf(err, errcap, "not a COBS classic index"); return NULL; }
+    orc_header_t hc; orc_compact_t cc; any_index ai;
+    size_t o;
+    if (orc_header_parse(index, index_len, &hc) == 0) {
+        ai.h = &hc; ai.c = NULL; ai.term_size = hc.term_size; ai.n_docs = hc.n_docs; o = hc.names_off;
+    } else if (orc_compact_parse(index, index_len, &cc) == 0) {
+        ai.h = NULL; ai.c = &cc; ai.term_size = cc.term_size; ai.n_docs = cc.n_docs; o = cc.names_off;
+    } else { snprintf(err, errcap, "not a COBS classic or compact index"); return NULL; }
+    struct { uint32_t n_docs; } h = { ai.n_docs };
     const char** names = (const char**)malloc(((size_t)h.n_docs + 1) * sizeof(char*));
     size_t* nlen = (size_t*)malloc(((size_t)h.n_docs + 1) * sizeof(size_t));
-    size_t o = h.names_off;
     for (uint32_t d = 0; d < h.n_docs; d++) {
         const uint8_t* nl = memchr(index + o, '\n', index_len - o);
         names[d] = (const char*)index + o; nlen[d] = (size_t)(nl - (index + o)); o += nlen[d] + 1;
@@ -285,7 +376,7 @@ char* orc_query_file(const uint8_t* index, size_t index_len, const char* fasta, 
         p += ll + (nl ? 1 : 0);
         if (ll == 0) continue;
         if (line[0] == '>' || line[0] == ';') {
-            rc = flush_record(&out, index, &h, names, nlen, hdr.p, hdr.n, seq.p, seq.n, threshold, num_results, err, errcap);
+            rc = flush_record(&out, index, &ai, names, nlen, hdr.p, hdr.n, seq.p, seq.n, threshold, num_results, err, errcap);
             hdr.n = 0; sb_put(&hdr, "*", 1); sb_put(&hdr, line + 1, ll - 1);
             seq.n = 0; seq.p[0] = 0;
         } else {
@@ -293,7 +384,7 @@ char* orc_query_file(const uint8_t* index, size_t index_len, const char* fasta, 
         }
     }
     if (rc == 0)
-        rc = flush_record(&out, index, &h, names, nlen, hdr.p, hdr.n, seq.p, seq.n, threshold, num_results, err, errcap);
+        rc = flush_record(&out, index, &ai, names, nlen, hdr.p, hdr.n, seq.p, seq.n, threshold, num_results, err, errcap);
     free(seq.p); free(hdr.p); free(names); free(nlen);
     if (rc) { free(out.p); return NULL; }
     if (out_len) *out_len = out.n;

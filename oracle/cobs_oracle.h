@@ -63,6 +63,27 @@ int  orc_scores(const uint8_t* matrix, uint64_t stride, const orc_header_t* h,
 size_t orc_select(const uint32_t* scores, uint32_t n_docs, uint64_t num_terms,
                   double threshold, size_t num_results, orc_hit_t* hits);
 
+/* ---- compact index ("COMPACT_INDEX"): a page-aligned concatenation of classic
+ * sub-indexes, each page_size bytes (= page_size*8 documents) wide with its own
+ * (signature_size, num_hashes).  Phylign does not use this format; layout
+ * restated from upstream cobs/file/compact_index_header.{hpp,cpp}, unpinned. */
+typedef struct {
+    uint32_t term_size;
+    uint8_t  canonicalize;
+    uint32_t n_parts;
+    uint32_t n_docs;
+    uint64_t page_size;
+    size_t   params_off;    /* n_parts x {u64 signature_size, u64 num_hashes} */
+    size_t   names_off;
+    size_t   data_off;      /* first byte of part 0; part i follows part i-1 */
+} orc_compact_t;
+int  orc_compact_parse(const uint8_t* buf, size_t len, orc_compact_t* c);
+uint8_t* orc_compact_alloc(uint32_t term_size, uint8_t canon, uint64_t page_size, uint32_t n_parts,
+                           const uint64_t* sig_sizes, const uint64_t* num_hashes, uint32_t n_docs,
+                           const char* const* names, size_t* total_len, size_t* data_off);
+int  orc_scores_compact(const uint8_t* index, const orc_compact_t* c, const char* seq, size_t len,
+                        uint32_t* scores);
+
 /* whole `cobs query -i index -f fasta -t threshold` restatement: returns a
  * malloc'd NUL-terminated text (COBS stdout) or NULL (error text in err). */
 char* orc_query_file(const uint8_t* index, size_t index_len,

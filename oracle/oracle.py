@@ -20,6 +20,12 @@ class Header(C.Structure):
                 ("data_off", C.c_size_t), ("layout", C.c_int)]
 
 
+class Compact(C.Structure):
+    _fields_ = [("term_size", C.c_uint32), ("canonicalize", C.c_uint8), ("n_parts", C.c_uint32),
+                ("n_docs", C.c_uint32), ("page_size", C.c_uint64), ("params_off", C.c_size_t),
+                ("names_off", C.c_size_t), ("data_off", C.c_size_t)]
+
+
 class Hit(C.Structure):
     _fields_ = [("doc", C.c_uint32), ("score", C.c_uint32)]
 
@@ -53,6 +59,11 @@ def lib():
         L.orc_query_file.restype = C.c_void_p
         L.orc_query_file.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_double, C.c_size_t,
                                      C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+        L.orc_compact_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Compact)]
+        L.orc_compact_alloc.restype = C.c_void_p
+        L.orc_compact_alloc.argtypes = [C.c_uint32, C.c_uint8, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                        C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.orc_scores_compact.argtypes = [C.c_void_p, C.POINTER(Compact), C.c_char_p, C.c_size_t, C.c_void_p]
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_synth_row.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
@@ -108,6 +119,40 @@ def make_index(term_size, canonicalize, signature_size, num_hashes, names, matri
         assert m.size == tot.value - off.value, (m.shape, tot.value - off.value)
         buf[off.value:] = m.reshape(-1)
     return buf
+
+
+def make_compact(term_size, canonicalize, page_size, sig_sizes, num_hashes, names, matrices=None):
+    """Build a complete .cobs_compact image.  matrices: optional list of uint8 arrays
+    [sig_sizes[p], page_size] (sub-index p holds documents p*page_size*8 ...)."""
+    import numpy as np
+    n, parts = len(names), len(sig_sizes)
+    arr = (C.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    sig = np.asarray(sig_sizes, dtype=np.uint64)
+    nh = np.asarray(num_hashes, dtype=np.uint64)
+    tot, off = C.c_size_t(), C.c_size_t()
+    p = lib().orc_compact_alloc(term_size, canonicalize, page_size, parts, sig.ctypes.data, nh.ctypes.data, n, arr,
+                                C.byref(tot), C.byref(off))
+    if not p:
+        raise MemoryError
+    buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(tot.value,)).copy()
+    _libc.free(p)
+    if matrices is not None:
+        o = off.value
+        for m, s in zip(matrices, sig_sizes):
+            m = np.ascontiguousarray(m, dtype=np.uint8)
+            assert m.shape == (s, page_size)
+            buf[o:o + m.size] = m.reshape(-1)
+            o += m.size
+    return buf
+
+
+def compact_parse(buf) -> Compact:
+    import numpy as np
+    a = np.frombuffer(buf, dtype=np.uint8)
+    c = Compact()
+    if lib().orc_compact_parse(a.ctypes.data, a.size, C.byref(c)) != 0:
+        raise ValueError("not a COBS compact index")
+    return c
 
 
 def create_hashes(seq: bytes, k: int, canon: int, num_hashes: int):

@@ -29,7 +29,8 @@ class IndexInfo(C.Structure):
     _fields_ = [("term_size", C.c_uint32), ("canonicalize", C.c_uint32),
                 ("signature_size", C.c_uint64), ("num_hashes", C.c_uint32),
                 ("n_docs", C.c_uint32), ("row_bytes", C.c_uint64), ("stride", C.c_uint64),
-                ("device_bytes", C.c_uint64), ("header_layout", C.c_uint32), ("has_matrix", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("header_layout", C.c_uint32), ("has_matrix", C.c_uint32),
+                ("n_parts", C.c_uint32), ("reserved", C.c_uint32), ("page_size", C.c_uint64)]
 
 
 class Stats(C.Structure):

@@ -69,6 +69,10 @@ struct pm_index {
     uint8_t* d_matrix = nullptr;
     int g = 1;                         // lanes per row
     uint32_t slabs = 1;
+    // compact index: one sub-index per page column, each a matrix of its own
+    // (signature_size_p, num_hashes_p) that is page_size bytes wide; empty for classic
+    std::vector<pm_index*> parts;
+    uint64_t page_size = 0;
 };
 
 struct pm_queries {
@@ -304,39 +308,12 @@ struct Reader {
     }
 };
 
-static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool header_only, pm_index_t** out) {
-    // 1. header: read ahead until it parses
-    std::vector<uint8_t> head;
-    size_t want = 1 << 16;
-    ParsedHeader h;
-    for (;;) {
-        size_t old = head.size();
-        head.resize(want);
-        ssize_t r = rd.read_full(head.data() + old, want - old);
-        if (r < 0) return fail(PM_EIO, "read error on index stream: %s", strerror(errno));
-        head.resize(old + (size_t)r);
-        int rc = parse_header(head.data(), head.size(), h);
-        if (rc == 0) break;
-        if (rc < 0) return fail(PM_EFORMAT, "input is not a COBS classic index (magic/version/field check failed)");
-        if ((size_t)r < want - old) return fail(PM_EFORMAT, "index stream ended inside the header");
-        want *= 2;
-        if (want > (1ull << 31)) return fail(PM_EFORMAT, "classic index header larger than 2 GiB");
-    }
-    pm_index* ix = new pm_index();
-    take_names(ix, head.data(), h);
-    int rc = finish_index_shape(ix, h, layout, !header_only);
-    if (rc) { delete ix; return rc; }
-    if (header_only) { *out = ix; return PM_OK; }
-    const uint64_t rb = ix->info.row_bytes, S = h.sig, stride = ix->info.stride;
-    if (size_hint && size_hint != h.data_off + S * rb)
-        fprintf(stderr, "phylign_match: warning: --index-sizes %llu != header-implied %llu bytes\n",
-                (unsigned long long)size_hint, (unsigned long long)(h.data_off + S * rb));
-    rd.pending.assign(head.begin() + (long)h.data_off, head.end());
-    rd.pend_pos = 0;
-
-    // 2. matrix: double-buffered pinned chunks -> staging -> restride kernel
+// Streams S rows of rb bytes from the reader into ix->d_matrix (row stride
+// ix->info.stride): double-buffered pinned chunks -> staging -> re-stride kernel.
+static int stream_matrix(Reader& rd, pm_index* ix, uint64_t rb, uint64_t S) {
+    const uint64_t stride = ix->info.stride;
     const uint64_t chunk_rows = std::max<uint64_t>(1, (32ull << 20) / rb);
-    const size_t chunk_bytes = (size_t)(chunk_rows * rb);
+    const size_t chunk_bytes = (size_t)(std::min<uint64_t>(chunk_rows, S) * rb);
     uint8_t* hbuf[2] = {nullptr, nullptr};
     uint8_t* dbuf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -351,7 +328,7 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
         if (e_ != hipSuccess) {                                                           \
-            cleanup(); pm_index_free(ix);                                                 \
+            cleanup();                                                                    \
             return fail(PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_));                 \
         }                                                                                 \
     } while (0)
@@ -367,7 +344,7 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
         if (used[cur]) LCHK(hipEventSynchronize(ev[cur]));
         ssize_t r = rd.read_full(hbuf[cur], nbytes);
         if (r < 0 || (size_t)r != nbytes) {
-            cleanup(); pm_index_free(ix);
+            cleanup();
             return fail(PM_EIO, "index stream ended after %llu of %llu matrix bytes",
                         (unsigned long long)(row * rb + (r > 0 ? (uint64_t)r : 0)), (unsigned long long)(S * rb));
         }
@@ -380,6 +357,145 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
     LCHK(hipStreamSynchronize(g_ctx.copy_stream));
 #undef LCHK
     cleanup();
+    return PM_OK;
+}
+
+// Compact index header ("COBS:" "COMPACT_INDEX", upstream
+// cobs/file/compact_index_header.cpp; Phylign itself only uses classic indexes,
+// Snakefile:48 -- SURVEY.md 8f rank 3): u32 version, u32 term_size, u8
+// canonicalize, u32 n_parameters, u32 n_docs, u64 page_size, n_parameters x
+// {u64 signature_size, u64 num_hashes}, names, zero padding so that the closing
+// magic ends on a page boundary, "COMPACT_INDEX", then the sub-indexes.
+struct ParsedCompact {
+    uint32_t term_size = 0, n_parts = 0, n_docs = 0;
+    uint8_t canon = 0;
+    uint64_t page = 0;
+    std::vector<uint64_t> sig, nh;
+    size_t names_off = 0, data_off = 0;
+};
+static int parse_compact(const uint8_t* b, size_t len, ParsedCompact& c) {   // 0 ok, 1 need more, <0 bad
+    const size_t fixed = 18 + 4 + 4 + 1 + 4 + 4 + 8;
+    if (len < fixed) return 1;
+    size_t o = 18;
+    auto rd32 = [&](size_t at) { uint32_t v; memcpy(&v, b + at, 4); return v; };
+    auto rd64 = [&](size_t at) { uint64_t v; memcpy(&v, b + at, 8); return v; };
+    const uint32_t ver = rd32(o); o += 4;
+    c.term_size = rd32(o); o += 4;
+    c.canon = b[o]; o += 1;
+    c.n_parts = rd32(o); o += 4;
+    c.n_docs = rd32(o); o += 4;
+    c.page = rd64(o); o += 8;
+    if (ver != 1 || c.term_size == 0 || c.term_size > 4096 || c.canon > 1 || c.page == 0 || c.page > (1ull << 30) ||
+        c.n_parts == 0 || c.n_parts > (1u << 20) || (uint64_t)c.n_parts * c.page * 8 < c.n_docs) return -1;
+    if (len < o + (size_t)c.n_parts * 16) return 1;
+    c.sig.resize(c.n_parts); c.nh.resize(c.n_parts);
+    for (uint32_t p = 0; p < c.n_parts; ++p) {
+        c.sig[p] = rd64(o); c.nh[p] = rd64(o + 8); o += 16;
+        if (c.sig[p] == 0 || c.nh[p] == 0 || c.nh[p] > 64) return -1;
+    }
+    c.names_off = o;
+    for (uint32_t d = 0; d < c.n_docs; ++d) {
+        if (o >= len) return 1;
+        const void* nl = memchr(b + o, '\n', len - o);
+        if (!nl) return (len - o > (1u << 20)) ? -1 : 1;
+        o = (size_t)((const uint8_t*)nl - b) + 1;
+    }
+    const size_t names_end = o;
+    o += (size_t)((c.page - ((o + 13) % c.page)) % c.page);
+    if (o + 13 > len) return 1;
+    if (memcmp(b + o, "COMPACT_INDEX", 13) != 0) return -1;
+    (void)names_end;
+    c.data_off = o + 13;
+    return 0;
+}
+
+static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool header_only, pm_index_t** out) {
+    // 1. header: read ahead until it parses (classic or compact)
+    std::vector<uint8_t> head;
+    size_t want = 1 << 16;
+    ParsedHeader h;
+    ParsedCompact pc;
+    bool compact = false;
+    for (;;) {
+        size_t old = head.size();
+        head.resize(want);
+        ssize_t r = rd.read_full(head.data() + old, want - old);
+        if (r < 0) return fail(PM_EIO, "read error on index stream: %s", strerror(errno));
+        head.resize(old + (size_t)r);
+        compact = head.size() >= 18 && memcmp(head.data(), "COBS:", 5) == 0 && memcmp(head.data() + 5, "COMPACT_INDEX", 13) == 0;
+        int rc = compact ? parse_compact(head.data(), head.size(), pc) : parse_header(head.data(), head.size(), h);
+        if (rc == 0) break;
+        if (rc < 0) return fail(PM_EFORMAT, "input is not a COBS classic (or compact) index (magic/version/field check failed)");
+        if ((size_t)r < want - old) return fail(PM_EFORMAT, "index stream ended inside the header");
+        want *= 2;
+        if (want > (1ull << 31)) return fail(PM_EFORMAT, "index header larger than 2 GiB");
+    }
+    pm_index* ix = new pm_index();
+    if (!compact) {
+        take_names(ix, head.data(), h);
+        int rc = finish_index_shape(ix, h, layout, !header_only);
+        if (rc) { delete ix; return rc; }
+        if (header_only) { *out = ix; return PM_OK; }
+        const uint64_t rb = ix->info.row_bytes, S = h.sig;
+        if (size_hint && size_hint != h.data_off + S * rb)
+            fprintf(stderr, "phylign_match: warning: --index-sizes %llu != header-implied %llu bytes\n",
+                    (unsigned long long)size_hint, (unsigned long long)(h.data_off + S * rb));
+        rd.pending.assign(head.begin() + (long)h.data_off, head.end());
+        rd.pend_pos = 0;
+        rc = stream_matrix(rd, ix, rb, S);
+        if (rc) { pm_index_free(ix); return rc; }
+        *out = ix;
+        return PM_OK;
+    }
+    // ---- compact: names for all documents, one sub-index object per page column
+    {
+        ParsedHeader nh_;                       // reuse take_names through a classic-shaped view
+        nh_.n_docs = pc.n_docs; nh_.names_off = pc.names_off; nh_.data_off = pc.data_off;
+        take_names(ix, head.data(), nh_);
+    }
+    ix->page_size = pc.page;
+    ix->info.term_size = pc.term_size; ix->info.canonicalize = pc.canon; ix->info.n_docs = pc.n_docs;
+    ix->info.signature_size = pc.sig[0]; ix->info.num_hashes = (uint32_t)pc.nh[0];
+    ix->info.row_bytes = pc.page; ix->info.n_parts = pc.n_parts; ix->info.page_size = pc.page;
+    rd.pending.assign(head.begin() + (long)pc.data_off, head.end());
+    rd.pend_pos = 0;
+    for (uint32_t p = 0; p < pc.n_parts; ++p) {
+        pm_index* part = new pm_index();
+        ix->parts.push_back(part);
+        const uint64_t first = (uint64_t)p * pc.page * 8;
+        ParsedHeader ph;
+        ph.version = 1; ph.term_size = pc.term_size; ph.canon = pc.canon; ph.sig = pc.sig[p]; ph.nh = pc.nh[p];
+        ph.n_docs = first >= pc.n_docs ? 0u : (uint32_t)std::min<uint64_t>(pc.page * 8, pc.n_docs - first);
+        if (ph.n_docs == 0) {                     // page column without documents: skip its bytes, never searched
+            if (!header_only) {
+                std::vector<uint8_t> sink(1 << 20);
+                uint64_t left = pc.sig[p] * pc.page;
+                while (left) { ssize_t r = rd.read_full(sink.data(), (size_t)std::min<uint64_t>(left, sink.size())); if (r <= 0) break; left -= (uint64_t)r; }
+            }
+            part->info.n_docs = 0;
+            continue;
+        }
+        // rows of a sub-index are page_size bytes in the file whatever its document count
+        int rc = finish_index_shape(part, ph, layout, false);
+        part->info.row_bytes = pc.page;
+        if (rc == PM_OK && !header_only) {
+            pm_index_info_t& in = part->info;
+            const uint64_t sc = stride_compact(pc.page), sa = stride_aligned(pc.page);
+            uint64_t stride = (layout == PM_LAYOUT_COMPACT) ? sc : sa;
+            in.stride = stride; in.device_bytes = pc.sig[p] * stride;
+            part->g = (int)pow2ceil((std::min<uint64_t>(stride, 1024) + 15) / 16);
+            part->slabs = (uint32_t)((stride + 1023) / 1024);
+            hipError_t e = hipMalloc((void**)&part->d_matrix, in.device_bytes);
+            if (e != hipSuccess) rc = fail(PM_ENOMEM, "hipMalloc(%llu bytes) for sub-index %u failed: %s",
+                                           (unsigned long long)in.device_bytes, p, hipGetErrorString(e));
+            else { in.has_matrix = 1; rc = stream_matrix(rd, part, pc.page, pc.sig[p]); }
+        }
+        if (rc) { pm_index_free(ix); return rc; }
+        ix->info.device_bytes += part->info.device_bytes;
+    }
+    ix->info.has_matrix = header_only ? 0 : 1;
+    ix->info.stride = ix->parts[0]->info.stride;
+    (void)size_hint;
     *out = ix;
     return PM_OK;
 }
@@ -453,7 +569,7 @@ extern "C" int pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signa
 
 extern "C" int pm_index_plant(pm_index_t* ix, const uint64_t* rows, const uint32_t* docs, size_t n) {
     NEED_DEV();
-    if (!ix || !ix->d_matrix) return fail(PM_EINVAL, "index has no matrix");
+    if (!ix || !ix->d_matrix) return fail(PM_EINVAL, "index has no matrix (planting works on classic indexes)");
     if (n == 0) return PM_OK;
     for (size_t i = 0; i < n; ++i)
         if (rows[i] >= ix->info.signature_size || docs[i] >= ix->info.n_docs)
@@ -514,6 +630,7 @@ extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_doc
 extern "C" int pm_index_drop_matrix(pm_index_t* ix) {
     if (!ix) return fail(PM_EINVAL, "bad argument");
     if (ix->d_matrix) { hipFree(ix->d_matrix); ix->d_matrix = nullptr; }
+    for (pm_index* p : ix->parts) pm_index_drop_matrix(p);
     ix->info.has_matrix = 0; ix->info.device_bytes = 0;
     return PM_OK;
 }
@@ -537,6 +654,7 @@ extern "C" int pm_index_read_row(const pm_index_t* ix, uint64_t row, void* out) 
 extern "C" void pm_index_free(pm_index_t* ix) {
     if (!ix) return;
     if (ix->d_matrix) hipFree(ix->d_matrix);
+    for (pm_index* p : ix->parts) pm_index_free(p);
     delete ix;
 }
 
@@ -741,36 +859,52 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     NEED_DEV();
     if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
     if (!(threshold >= 0.0)) return fail(PM_EINVAL, "threshold must be >= 0");
+    // one scan unit per classic index or per sub-index of a compact index
+    struct Unit { const pm_index* ix; uint32_t slot, doc_base; bool prune; };
+    std::vector<Unit> units;
     for (size_t s = 0; s < n_idx; ++s) {
-        if (!idx[s] || !idx[s]->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
+        if (!idx[s]) return fail(PM_EINVAL, "index %zu is null", s);
         if (idx[s]->info.term_size != q->k)
             return fail(PM_EINVAL, "index %zu has term_size %u but the queries were parsed for %u", s, idx[s]->info.term_size, q->k);
+        if (idx[s]->parts.empty()) {
+            if (!idx[s]->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
+            units.push_back({idx[s], slot_base + (uint32_t)s, 0u, true});
+        } else {
+            // the n best documents of a compact index span its sub-indexes: cut when formatting
+            for (size_t p = 0; p < idx[s]->parts.size(); ++p) {
+                const pm_index* part = idx[s]->parts[p];
+                if (part->info.n_docs == 0) continue;
+                if (!part->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
+                units.push_back({part, slot_base + (uint32_t)s, (uint32_t)(p * idx[s]->page_size * 8), false});
+            }
+        }
     }
     const size_t nq = q->headers.size();
     hipStream_t st = g_ctx.stream;
     { int urc = upload_queries(q); if (urc) return urc; }
 
     // ---- launch plan: one scan launch per (lanes-per-row class, canonicalize,
-    // num_hashes) x counter-width class covers every batch of that class;
+    // num_hashes) x counter-width class covers every unit of that class;
     // rows wider than 1024 B (column slabs) get a launch of their own.
     struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; };
     std::vector<Group> groups;
-    for (size_t s = 0; s < n_idx; ++s) {
-        const pm_index* ix = idx[s];
+    for (size_t u = 0; u < units.size(); ++u) {
+        const pm_index* ix = units[u].ix;
         Group* gp = nullptr;
         if (ix->slabs == 1)
             for (auto& g : groups)
                 if (g.slabs == 1 && g.g == ix->g && g.canon == (int)ix->info.canonicalize && g.nh == ix->info.num_hashes) gp = &g;
         if (!gp) { groups.push_back({ix->g, (int)ix->info.canonicalize, ix->info.num_hashes, ix->slabs, {}}); gp = &groups.back(); }
-        gp->members.push_back(s);
+        gp->members.push_back(u);
     }
+    const size_t n_units = units.size();
     // ---- workspace (persistent, grow-only)
     if (!g_ctx.d_cnt) HIPCHK(hipMalloc((void**)&g_ctx.d_cnt, 8));
-    if (g_ctx.desc_cap < n_idx) {
+    if (g_ctx.desc_cap < n_units) {
         if (g_ctx.d_desc) hipFree(g_ctx.d_desc);
         if (g_ctx.h_desc) hipHostFree(g_ctx.h_desc);
         g_ctx.d_desc = nullptr; g_ctx.h_desc = nullptr; g_ctx.desc_cap = 0;
-        const size_t cap = std::max<size_t>(n_idx, 64);
+        const size_t cap = std::max<size_t>(n_units, 64);
         HIPCHK(hipMalloc((void**)&g_ctx.d_desc, cap * sizeof(BatchDesc)));
         HIPCHK(hipHostMalloc((void**)&g_ctx.h_desc, cap * sizeof(BatchDesc), hipHostMallocDefault));
         g_ctx.desc_cap = cap;
@@ -778,14 +912,15 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     {
         size_t o = 0;
         for (auto& g : groups)
-            for (size_t s : g.members) {
-                const pm_index* ix = idx[s];
+            for (size_t u : g.members) {
+                const pm_index* ix = units[u].ix;
                 BatchDesc& d = g_ctx.h_desc[o++];
                 d.matrix = ix->d_matrix; d.stride = ix->info.stride; d.sig_size = ix->info.signature_size;
                 d.barrett_m = barrett_m(ix->info.signature_size); d.n_docs = ix->info.n_docs;
-                d.slot = slot_base + (uint32_t)s; d.pad_ = 0;
+                d.slot = units[u].slot; d.doc_base = units[u].doc_base; d.prune = units[u].prune ? 1u : 0u;
             }
-        HIPCHK(hipMemcpyAsync(g_ctx.d_desc, g_ctx.h_desc, n_idx * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
+        if (n_units)
+            HIPCHK(hipMemcpyAsync(g_ctx.d_desc, g_ctx.h_desc, n_units * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
     }
     // per-query minimum score, cached on the query set per threshold value
     if (nq && (!q->d_thr || q->thr_for != threshold)) {
@@ -827,7 +962,7 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
         for (auto& g : groups) {
             RCHK(ensure_hashes(q, g.canon, g.nh, &d_h));
             uint64_t rowsum = 0;
-            for (size_t s : g.members) rowsum += idx[s]->info.row_bytes;
+            for (size_t u : g.members) rowsum += units[u].ix->info.row_bytes;
             for (int c = 0; c < 4; ++c) {
                 const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
                 if (e == b) continue;

@@ -23,7 +23,8 @@ struct BatchDesc {
     uint64_t barrett_m;         // floor(2^64 / S); 0 encodes S == 1
     uint32_t n_docs;
     uint32_t slot;
-    uint64_t pad_;
+    uint32_t doc_base;          // first document of this unit inside its index (compact sub-indexes)
+    uint32_t prune;             // 1: ScanArgs.prune_n applies to this unit
 };
 
 struct ScanArgs {

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
     // popcounts by xor-shuffles; the search for the cut is a bisection on the score.
     bool count_rec = false;          // lane 0 of a pruned query reports the unpruned count
     uint32_t full_count = 0;
-    if (a.prune_n > 0u && gridDim.y == 1) {
+    if (a.prune_n > 0u && bd.prune != 0u && gridDim.y == 1) {
         auto group_count = [&](const u32x4& m) -> uint32_t {
             uint32_t v = (uint32_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
             if (has) {
                 const int bit = __ffs((int)m) - 1;
                 m &= m - 1u;
-                doc = (uint32_t)(doc0 + 32u * w + (uint32_t)bit);
+                doc = bd.doc_base + (uint32_t)(doc0 + 32u * w + (uint32_t)bit);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const uint32_t word = (w == 0) ? pl[p].x : (w == 1) ? pl[p].y : (w == 2) ? pl[p].z : pl[p].w;

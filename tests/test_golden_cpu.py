@@ -325,3 +325,37 @@ def test_fix_query_rules_and_awk_fixed_point(tmp_path):
     merged = open(os.path.join(GOLD, "reads", "reads_1___reads_2___reads_3___reads_4.fa"), "rb").read()
     assert merged.count(b">") == 40 and merged.startswith(b">1A\nTTTGAAATCC") and b">4J\n" in merged
     assert set(merged.replace(b">", b"").replace(b"\n", b"")) <= set(b"ACGT0123456789ABCDEFGHIJ")
+
+
+def test_oracle_compact_index_bruteforce(oracle):
+    """the oracle's compact-index restatement vs an independent pure-Python evaluation"""
+    rng = np.random.default_rng(0)
+    page, sigs, nh, nd, k = 16, [50, 70, 40], [1, 2, 1], 300, 5
+    mats = []
+    for p, s in enumerate(sigs):
+        bits = rng.random((s, page * 8)) < 0.4
+        if p * 128 + 128 > nd:
+            bits[:, nd - p * 128:] = False
+        mats.append(np.packbits(bits, axis=1, bitorder="little"))
+    names = [f"a_D{i}" for i in range(nd)]
+    idx = oracle.make_compact(k, 1, page, sigs, nh, names, mats)
+    c = oracle.compact_parse(idx)
+    assert (c.n_parts, c.n_docs, c.page_size) == (3, nd, page) and c.data_off % page == 0
+    assert bytes(idx[:18]) == b"COBS:COMPACT_INDEX" and bytes(idx[c.data_off - 13:c.data_off]) == b"COMPACT_INDEX"
+    seq = "ACGTTGCAACGTAGCTAGCTAGGATC"
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    exp = [0] * nd
+    for i in range(len(seq) - k + 1):
+        km = seq[i:i + k]
+        can = min(km, "".join(comp[x] for x in reversed(km))).encode()
+        for p, s in enumerate(sigs):
+            acc = np.full(page, 255, dtype=np.uint8)
+            for j in range(nh[p]):
+                acc &= mats[p][oracle.xxh64(can, j) % s]
+            b = np.unpackbits(acc, bitorder="little")
+            for d in range(128):
+                if p * 128 + d < nd:
+                    exp[p * 128 + d] += int(b[d])
+    lines = oracle.query_file(idx, f">q\n{seq}\n".encode(), 0.3).decode().split("\n")
+    want = sorted([(d, s) for d, s in enumerate(exp) if s >= oracle.threshold(0.3, len(seq) - k + 1)], key=lambda t: (-t[1], t[0]))
+    assert lines[0] == f"*q\t{len(want)}" and lines[1:-1] == [f"a_D{d}\t{s}" for d, s in want]

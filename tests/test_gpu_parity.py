@@ -249,3 +249,51 @@ def test_on_device_top_n_with_ties(pm, oracle, n_docs):
         from phylign_amd import postprocess as P
         text = pm.format_hits(ix, q, got, slot=0, nb_best_hits=n).decode()
         assert text == P.filter_text(oracle.query_file(index, fasta, 0.7).decode(), n)
+
+
+@pytest.mark.parametrize("page,n_docs,sigs,nhs", [
+    (16, 300, [500, 700, 400], [1, 2, 1]),           # 128 documents per sub-index, last one partly filled
+    (64, 1024, [900, 800], [1, 1]),
+    (128, 2500, [600, 500, 400], [2, 1, 3]),
+    (2048, 20000, [300, 200], [1, 1]),               # 16384 documents per sub-index: column slabs
+])
+def test_compact_index_text_bit_exact(pm, oracle, page, n_docs, sigs, nhs, tmp_path):
+    """COMPACT_INDEX files: sub-indexes with their own signature sizes and hash counts"""
+    from helpers import doc_names
+    from phylign_amd import postprocess as P
+    rng = np.random.default_rng(page + n_docs)
+    queries = [(f"c{i} x", rand_seq(rng, 150)) for i in range(14)]
+    per = page * 8
+    mats = []
+    for p, S in enumerate(sigs):
+        bits = rng.random((S, per)) < 0.2
+        lo = p * per
+        if lo + per > n_docs:
+            bits[:, max(0, n_docs - lo):] = False
+        mats.append(np.packbits(bits, axis=1, bitorder="little"))
+    for qi in range(0, 14, 2):                       # plant across sub-indexes
+        seq = queries[qi][1].encode()
+        for d, frac in ((int(rng.integers(0, n_docs)), 1.0), (int(rng.integers(0, n_docs)), 0.8), (n_docs - 1, 0.75), (0, 0.7)):
+            p, dl = d // per, d % per
+            hs = oracle.create_hashes(seq, 31, 1, nhs[p]).reshape(-1, nhs[p])
+            for t in range(int(np.ceil(frac * len(hs)))):
+                for j in range(nhs[p]):
+                    mats[p][int(hs[t, j]) % sigs[p], dl >> 3] |= np.uint8(1 << (dl & 7))
+    names = doc_names(rng, n_docs)
+    index = oracle.make_compact(31, 1, page, sigs, nhs, names, mats)
+    fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
+    exp = oracle.query_file(index, fasta, 0.7)
+    assert exp.count(b"\n") > 14 + 7 * 3
+    for layout in (1, 2):
+        ix = pm.Index.load_mem(index, layout=layout)
+        info = ix.info
+        assert (info.n_parts, info.page_size, info.n_docs) == (len(sigs), page, n_docs)
+        assert pm.query_text(ix, fasta, 0.7) == exp
+        assert pm.query_text(ix, fasta, 0.7, nb_best_hits=2).decode() == P.filter_text(exp.decode(), 2)
+    p = tmp_path / "x.cobs_compact"
+    p.write_bytes(bytes(index))
+    ix = pm.Index.load_file(str(p))
+    assert pm.query_text(ix, fasta, 0.0) == oracle.query_file(index, fasta, 0.0)
+    q = pm.Queries(fasta)
+    st = pm.search([ix], q, 0.7).stats
+    assert st.algorithmic_bytes == 14 * 120 * sum(nh * page for nh in nhs)

@@ -114,7 +114,7 @@ def main():
     import torch.distributed as dist
     from phylign_amd import _lib as pm
     from phylign_amd import workload as W
-    from phylign_amd.dist import gather_hits
+    from phylign_amd.dist import PackedGather
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -179,6 +179,9 @@ def main():
             torch.cuda.synchronize()
 
     last = {}
+    pg_dev = "cuda" if backend == "nccl" else "cpu"
+    packed = PackedGather(1 << 16, pg_dev)          # 64 Ki records (1 MiB) per rank in one collective
+    stage = torch.zeros((1 << 16, 4), dtype=torch.int32, device="cuda")   # used when the gather runs on CPU tensors
 
     phase = {"search": 0.0, "gather": 0.0, "host": 0.0}
 
@@ -186,10 +189,18 @@ def main():
         t_a = time.perf_counter()
         res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
         st = res.stats
-        buf = torch.empty((int(st.n_hits), 4), dtype=torch.int32, device="cuda")
+        n_local = int(st.n_hits)
         t_b = time.perf_counter()
-        res.copy_hits_device(buf.data_ptr(), int(st.n_hits))
-        g = gather_hits(buf if backend == "nccl" else buf.cpu(), dst=0)
+        if n_local <= packed.cap:
+            dst_t = packed.records_view() if pg_dev == "cuda" else stage
+            res.copy_hits_device(dst_t.data_ptr(), n_local)
+            if pg_dev != "cuda":
+                packed.records_view()[:n_local] = stage[:n_local].cpu()
+            g = packed.gather(n_local)
+        else:
+            buf = torch.empty((n_local, 4), dtype=torch.int32, device="cuda")
+            res.copy_hits_device(buf.data_ptr(), n_local)
+            g = packed.gather(n_local, overflow=buf if pg_dev == "cuda" else buf.cpu())
         t_c = time.perf_counter()
         host = None
         if rank == 0:

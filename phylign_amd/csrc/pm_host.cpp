@@ -591,7 +591,7 @@ extern "C" int pm_index_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
     NEED_DEV();
     if (!ix || !ix->d_matrix || !ms || !bytes || n_groups == 0) return fail(PM_EINVAL, "bad argument");
     if (ix->slabs != 1) return fail(PM_EINVAL, "probe supports rows up to 1024 bytes");
-    lookups_per_group = (lookups_per_group + 7) / 8 * 8;
+    lookups_per_group = (lookups_per_group + 15) / 16 * 16;
     uint32_t* sink = nullptr;
     HIPCHK(hipMalloc((void**)&sink, 4));
     hipEvent_t e0, e1;

@@ -539,7 +539,7 @@ hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t
 // G lanes per row, 8 gathers in flight per lane) with the counting replaced by
 // one XOR per load.  Used only to measure what the memory system delivers for
 // this pattern; not part of the matching path.
-template <int G>
+template <int G, int U>
 __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict__ matrix, uint64_t stride,
                                                        uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink)
 {
@@ -549,32 +549,41 @@ __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict_
     u32x4 acc = (u32x4)(0u);
     uint64_t state = splitmix64(group * 0x9E3779B97F4A7C15ULL + 1);
     const bool active = (uint64_t)c * 16 < stride;
-    for (uint64_t i = 0; i < lookups_per_group; i += 8) {
-        u32x4 v[8];
+    for (uint64_t i = 0; i < lookups_per_group; i += U) {
+        u32x4 v[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < U; ++k) {
             state = state * 6364136223846793005ULL + 1442695040888963407ULL;
             const uint64_t r = __umul64hi(state, n_rows);
             v[k] = (u32x4)(0u);
             if (active) v[k] = *reinterpret_cast<const u32x4*>(matrix + r * stride + (uint64_t)c * 16);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc ^= v[k];
+        for (int k = 0; k < U; ++k) acc ^= v[k];
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;   // keeps the loads alive
+}
+template <int G>
+static void probe_launch_u(int unroll, dim3 grid, hipStream_t st, const uint8_t* matrix, uint64_t stride,
+                           uint64_t n_rows, uint64_t per, uint32_t* sink) {
+    if (unroll == 4)       hipLaunchKernelGGL((k_probe_gather<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink);
+    else if (unroll == 16) hipLaunchKernelGGL((k_probe_gather<G, 16>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink);
+    else                   hipLaunchKernelGGL((k_probe_gather<G, 8>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink);
 }
 hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
                                uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st) {
     const uint64_t threads = groups * (uint64_t)g;
     dim3 grid((uint32_t)((threads + 255) / 256));
+    int unroll = 8;
+    if (const char* u = getenv("PM_PROBE_UNROLL")) unroll = atoi(u);
     switch (g) {
-        case 1:  hipLaunchKernelGGL(k_probe_gather<1>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 2:  hipLaunchKernelGGL(k_probe_gather<2>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 4:  hipLaunchKernelGGL(k_probe_gather<4>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 8:  hipLaunchKernelGGL(k_probe_gather<8>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 16: hipLaunchKernelGGL(k_probe_gather<16>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 32: hipLaunchKernelGGL(k_probe_gather<32>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 64: hipLaunchKernelGGL(k_probe_gather<64>, grid, dim3(256), 0, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 1:  probe_launch_u<1>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 2:  probe_launch_u<2>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 4:  probe_launch_u<4>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 8:  probe_launch_u<8>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 16: probe_launch_u<16>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 32: probe_launch_u<32>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
+        case 64: probe_launch_u<64>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

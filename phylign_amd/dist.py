@@ -38,3 +38,48 @@ def gather_hits(local, dst=0, group=None):
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst, group=group)]):
             w.wait()
     return None
+
+
+class PackedGather:
+    """One-collective form of gather_hits for a step loop: every rank owns a fixed
+    [cap + 1, 4] int32 buffer whose row 0 carries its record count; one
+    `dist.gather` moves all of them to rank 0 (with RCCL: 7 peer-to-root
+    transfers over 7 distinct xGMI links).  A rank with more than `cap` records
+    announces its count and ships the records in a second, point-to-point
+    message, so the result never depends on `cap`."""
+
+    def __init__(self, cap, device, group=None):
+        self.cap, self.group, self.device = int(cap), group, device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.pack = torch.zeros((self.cap + 1, 4), dtype=torch.int32, device=device)
+        self.recv = [torch.zeros_like(self.pack) for _ in range(self.world)] if self.rank == 0 and self.world > 1 else None
+
+    def records_view(self):
+        """rows 1.. of the local buffer: the place to copy up to `cap` records into"""
+        return self.pack[1:]
+
+    def gather(self, count, overflow=None, dst=0):
+        """count: number of valid rows in records_view(), or the true count when
+        it exceeds cap and `overflow` (int32 [count, 4]) holds all records."""
+        assert dst == 0
+        if self.world == 1:
+            return overflow if count > self.cap else self.pack[1:1 + count]
+        self.pack[0, 0] = int(count)
+        dist.gather(self.pack, self.recv, dst=0, group=self.group)
+        if self.rank != 0:
+            if count > self.cap:
+                dist.send(overflow.contiguous(), 0, group=self.group)
+            return None
+        counts = torch.stack([r[0, 0] for r in self.recv]).cpu().tolist()
+        parts = []
+        for r, c in enumerate(counts):
+            if c <= self.cap:
+                parts.append(self.recv[r][1:1 + c])
+            elif r == 0:
+                parts.append(overflow)
+            else:
+                buf = torch.empty((c, 4), dtype=torch.int32, device=self.device)
+                dist.recv(buf, r, group=self.group)
+                parts.append(buf)
+        return torch.cat(parts, dim=0)

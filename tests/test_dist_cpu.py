@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, swap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,6 +31,8 @@ def _worker(rank, world, port, outdir):
     # every rank fabricates deterministic "hits" for its own batches
     rng = np.random.default_rng(100 + rank)
     n = [37, 0][rank] if world == 2 else 5          # one rank sends nothing: empty send path
+    if swap:
+        n = [0, 37][rank]                           # the non-root rank overflows the packed buffer
     rec = np.zeros((n, 4), dtype=np.int32)
     rec[:, 0] = rng.integers(0, 1000, size=n)
     rec[:, 1] = rng.integers(0, 4000, size=n)
@@ -39,6 +41,18 @@ def _worker(rank, world, port, outdir):
     g = gather_hits(torch.from_numpy(rec), dst=0)
     g2 = gather_hits(torch.from_numpy(rec[::-1].copy()), dst=0)   # a second round on the same group
     np.save(os.path.join(outdir, f"sent{rank}.npy"), rec)
+    # one-collective packed form, including the overflow path (cap smaller than rank 0's count)
+    from phylign_amd.dist import PackedGather
+    for cap, tag in ((64, "fit"), (10, "ovf")):
+        pg = PackedGather(cap, "cpu")
+        t = torch.from_numpy(rec)
+        if n <= cap:
+            pg.records_view()[:n] = t
+            out = pg.gather(n)
+        else:
+            out = pg.gather(n, overflow=t)
+        if rank == 0:
+            np.save(os.path.join(outdir, f"packed_{tag}.npy"), out.numpy())
     if rank == 0:
         assert g is not None and g2 is not None
         np.save(os.path.join(outdir, "gathered.npy"), g.numpy())
@@ -49,14 +63,17 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_gather_hits_world2_gloo(tmp_path):
+@pytest.mark.parametrize("swap", [False, True])
+def test_gather_hits_world2_gloo(tmp_path, swap):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), swap), nprocs=2, join=True)
     sent = [np.load(tmp_path / f"sent{r}.npy") for r in range(2)]
     got = np.load(tmp_path / "gathered.npy")
     assert got.shape == (37, 4) and np.array_equal(got, np.concatenate(sent))
     got2 = np.load(tmp_path / "gathered2.npy")
     assert np.array_equal(got2, np.concatenate([s[::-1] for s in sent]))
+    for tag in ("fit", "ovf"):
+        assert np.array_equal(np.load(tmp_path / f"packed_{tag}.npy"), np.concatenate(sent))
 
 
 def test_assign_batches_is_a_balanced_partition():

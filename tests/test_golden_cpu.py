@@ -359,3 +359,34 @@ def test_oracle_compact_index_bruteforce(oracle):
     lines = oracle.query_file(idx, f">q\n{seq}\n".encode(), 0.3).decode().split("\n")
     want = sorted([(d, s) for d, s in enumerate(exp) if s >= oracle.threshold(0.3, len(seq) - k + 1)], key=lambda t: (-t[1], t[0]))
     assert lines[0] == f"*q\t{len(want)}" and lines[1:-1] == [f"a_D{d}\t{s}" for d, s in want]
+
+
+# -------------------------------- product header readers (host-only entry point)
+def test_product_header_reader_classic_and_compact(oracle):
+    """pm_index_load_header_mem parses headers without a GPU: both classic field orders,
+    compact headers, and rejects malformed input with PM_EFORMAT (-5)."""
+    from phylign_amd import _lib as pm
+    names = [f"{i:05x}_SAM{i}" for i in range(37)]
+    idx = oracle.make_index(31, 1, 1000, 2, names)
+    ix = pm.Index.load_header_mem(idx)
+    info = ix.info
+    assert (info.term_size, info.canonicalize, info.signature_size, info.num_hashes, info.n_docs, info.row_bytes,
+            info.header_layout, info.has_matrix, info.n_parts) == (31, 1, 1000, 2, 37, 5, 0, 0, 0)
+    assert [ix.doc_name(d) for d in (0, 36)] == [names[0], names[36]]
+    b = bytearray(idx)                       # SURVEY.md appendix A.1 order: sig, hashes, n_docs
+    o = 18 + 9
+    b[o:o + 20] = b[o + 4:o + 12] + b[o + 12:o + 20] + b[o:o + 4]
+    ix2 = pm.Index.load_header_mem(bytes(b))
+    assert (ix2.info.signature_size, ix2.info.num_hashes, ix2.info.n_docs, ix2.info.header_layout) == (1000, 2, 37, 1)
+    cidx = oracle.make_compact(31, 1, 64, [100, 90], [1, 3], [f"x_{i}" for i in range(700)])
+    cx = pm.Index.load_header_mem(cidx)
+    assert (cx.info.n_parts, cx.info.page_size, cx.info.n_docs, cx.info.row_bytes) == (2, 64, 700, 64)
+    assert cx.doc_name(699) == "x_699"
+    for bad in (b"", b"COBS:", b"COBS:CLASSIC_INDEX" + bytes(40), b"COBS:XXXXXXX_INDEX" + bytes(200),
+                bytes(idx[:200]), bytes(idx[:18]) + b"\x02" + bytes(idx[19:])):
+        with pytest.raises(pm.PMError) as e:
+            pm.Index.load_header_mem(bad)
+        assert e.value.code == -5, bad[:30]
+    with pytest.raises(pm.PMError) as e:
+        pm.Index.load_mem(idx)               # the matrix needs the GPU
+    assert e.value.code == -2

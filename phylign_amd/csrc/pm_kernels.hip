@@ -541,7 +541,8 @@ hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t
 // this pattern; not part of the matching path.
 template <int G, int U>
 __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict__ matrix, uint64_t stride,
-                                                       uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink)
+                                                       uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink,
+                                                       int mode)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / G;
@@ -549,12 +550,28 @@ __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict_
     u32x4 acc = (u32x4)(0u);
     uint64_t state = splitmix64(group * 0x9E3779B97F4A7C15ULL + 1);
     const bool active = (uint64_t)c * 16 < stride;
+    // mode 1: ascending stratified rows; mode 2: ascending order statistics of uniform rows
+    // (what a query sees when its k-mers are visited in row order) -- locality experiments
+    float total = 0.f, run = 0.f;
+    if (mode == 2) {
+        uint64_t st2 = state;
+        for (uint64_t i = 0; i <= lookups_per_group; ++i) {
+            st2 = st2 * 6364136223846793005ULL + 1442695040888963407ULL;
+            total += -__logf(((float)(uint32_t)(st2 >> 40) + 1.f) * (1.f / 16777217.f));
+        }
+    }
     for (uint64_t i = 0; i < lookups_per_group; i += U) {
         u32x4 v[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             state = state * 6364136223846793005ULL + 1442695040888963407ULL;
-            const uint64_t r = __umul64hi(state, n_rows);
+            uint64_t r = __umul64hi(state, n_rows);
+            if (mode == 1) r = (uint64_t)(((double)(i + k) + (double)(state >> 11) * (1.0 / 9007199254740992.0)) / (double)lookups_per_group * (double)n_rows);
+            if (mode == 2) {
+                run += -__logf(((float)(uint32_t)(state >> 40) + 1.f) * (1.f / 16777217.f));
+                r = (uint64_t)((double)(run / total) * (double)(n_rows - 1));
+            }
+            if (r >= n_rows) r = n_rows - 1;
             v[k] = (u32x4)(0u);
             if (active) v[k] = *reinterpret_cast<const u32x4*>(matrix + r * stride + (uint64_t)c * 16);
         }
@@ -566,9 +583,11 @@ __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict_
 template <int G>
 static void probe_launch_u(int unroll, dim3 grid, hipStream_t st, const uint8_t* matrix, uint64_t stride,
                            uint64_t n_rows, uint64_t per, uint32_t* sink) {
-    if (unroll == 4)       hipLaunchKernelGGL((k_probe_gather<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink);
-    else if (unroll == 16) hipLaunchKernelGGL((k_probe_gather<G, 16>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink);
-    else                   hipLaunchKernelGGL((k_probe_gather<G, 8>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink);
+    int mode = 0;
+    if (const char* m = getenv("PM_PROBE_MODE")) mode = atoi(m);
+    if (unroll == 4)       hipLaunchKernelGGL((k_probe_gather<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
+    else if (unroll == 16) hipLaunchKernelGGL((k_probe_gather<G, 16>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
+    else                   hipLaunchKernelGGL((k_probe_gather<G, 8>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
 }
 hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
                                uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st) {

@@ -1122,6 +1122,14 @@ extern "C" void pm_result_free(pm_result_t* r) {
 // nb_best_hits >= 0 fuses scripts/postprocess_cobs.py:16-39: header untouched,
 // each name cut to "_" + what follows its first '_', the first n lines kept plus
 // later lines whose score equals the n-th score.
+static inline void append_tab_uint_nl(std::string& out, uint64_t v) {     // "\t<v>\n"
+    char buf[24]; int n = 0;
+    do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    out.push_back('\t');
+    while (n) out.push_back(buf[--n]);
+    out.push_back('\n');
+}
+
 extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
                               const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
                               int64_t nb_best, char** text, size_t* len) {
@@ -1134,8 +1142,7 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
             return fail(PM_EINVAL, "hit record (query %u, doc %u) out of range for this index/query set", h.query, h.doc);
     order_hits(mine.data(), mine.size());
     std::string out;
-    out.reserve(mine.size() * 24 + nq * 24);
-    char num[32];
+    out.reserve(mine.size() * 28 + nq * 24);
     size_t p = 0;
     for (size_t qi = 0; qi < nq; ++qi) {
         size_t e = p;
@@ -1143,14 +1150,14 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
         size_t total = e - p;
         if (p < e && mine[p].doc == PM_DOC_COUNT) { total = mine[p].score; ++p; }   // pruned on the GPU
         out.push_back('*'); out += q->headers[qi];
-        out.append(num, (size_t)snprintf(num, sizeof num, "\t%zu\n", total));
+        append_tab_uint_nl(out, total);
         uint32_t min_kmers = 0;
         for (size_t i = p; i < e; ++i) {
             const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
             const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
             if (nb_best < 0) {
                 out.append(nm, nl);
-                out.append(num, (size_t)snprintf(num, sizeof num, "\t%u\n", mine[i].score));
+                append_tab_uint_nl(out, mine[i].score);
                 continue;
             }
             const int64_t rank = (int64_t)(i - p) + 1;      // 1-based like the post-filter's counter
@@ -1167,7 +1174,7 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
             else keep = mine[i].score == min_kmers;
             if (keep) {
                 out.append(us, nl - (size_t)(us - nm));
-                out.append(num, (size_t)snprintf(num, sizeof num, "\t%u\n", mine[i].score));
+                append_tab_uint_nl(out, mine[i].score);
             }
         }
         p = e;

@@ -1,0 +1,57 @@
+"""Randomised differential test: the HIP path vs the oracle on random index shapes,
+k-mer sizes, hash counts, thresholds, query lengths and formats (seeded, 60 cases)."""
+import numpy as np
+import pytest
+
+from helpers import build_case, doc_names, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_case_text_identical(pm, oracle, seed):
+    from phylign_amd import postprocess as P
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([5, 11, 15, 21, 27, 31, 31, 31, 32, 33, 47]))
+    canon = int(rng.integers(0, 2))
+    nh = int(rng.choice([1, 1, 1, 2, 3, 4]))
+    n_docs = int(rng.choice([1, 7, 8, 9, 63, 64, 65, 127, 128, 129, 200, 511, 512, 513, 1000, 1024, 1025,
+                             2047, 3000, 4000, 4097, 8191, 8192, 8193, 12000]))
+    S = int(rng.integers(50, 4000))
+    thr = float(rng.choice([0.0, 0.2, 0.5, 0.7, 0.7, 0.7, 0.9, 1.0]))
+    nq = int(rng.integers(1, 25))
+    lens = [int(rng.choice([k, k + 1, k + 6, k + 7, k + 8, 60, 100, 150, 150, 200, 400, 1100])) for _ in range(nq)]
+    lens = [max(l, k) for l in lens]
+    queries = [(f"r{i}" + (" c o m" if i % 4 == 0 else ""), rand_seq(rng, lens[i])) for i in range(nq)]
+    plant = [(int(rng.integers(0, nq)), int(rng.integers(0, n_docs)), float(rng.choice([1.0, 0.9, 0.71, 0.7, 0.69, 0.5, 0.2])))
+             for _ in range(int(rng.integers(0, 40)))]
+    density = float(rng.choice([0.02, 0.25, 0.5]))
+    compact = seed % 5 == 4 and n_docs >= 64
+    if not compact:
+        index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, k=k, canon=canon, num_hashes=nh,
+                                     density=density, plant=plant)
+    else:
+        page = int(rng.choice([8, 16, 32]))
+        per = page * 8
+        parts = (n_docs + per - 1) // per
+        sigs = [int(rng.integers(50, 900)) for _ in range(parts)]
+        nhs = [int(rng.integers(1, 4)) for _ in range(parts)]
+        mats = []
+        for p in range(parts):
+            bits = rng.random((sigs[p], per)) < density
+            if p * per + per > n_docs:
+                bits[:, n_docs - p * per:] = False
+            mats.append(np.packbits(bits, axis=1, bitorder="little"))
+        for qi, d, frac in plant:
+            p, dl = d // per, d % per
+            hs = oracle.create_hashes(queries[qi][1].encode(), k, canon, nhs[p]).reshape(-1, nhs[p])
+            for t in range(int(np.ceil(frac * len(hs)))):
+                for j in range(nhs[p]):
+                    mats[p][int(hs[t, j]) % sigs[p], dl >> 3] |= np.uint8(1 << (dl & 7))
+        index = oracle.make_compact(k, canon, page, sigs, nhs, doc_names(rng, n_docs), mats)
+        fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
+    exp = oracle.query_file(index, fasta, thr)
+    ix = pm.Index.load_mem(index, layout=int(rng.integers(0, 3)))
+    assert pm.query_text(ix, fasta, thr) == exp
+    n = int(rng.choice([1, 2, 5, 100]))
+    assert pm.query_text(ix, fasta, thr, nb_best_hits=n).decode() == P.filter_text(exp.decode(), n)

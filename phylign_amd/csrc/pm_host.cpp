@@ -78,6 +78,7 @@ struct pm_index {
 struct pm_queries {
     uint32_t k = 0;
     std::vector<std::string> headers;       // header line without its first byte
+    std::vector<uint8_t> headerless;        // 1: sequence lines came before any header ("\tN" is printed without '*')
     std::string seqs;                       // packed sequences (host copy, for the 04_filter emit)
     std::vector<uint64_t> seq_off;          // n_queries + 1
     std::vector<uint32_t> n_terms;
@@ -685,6 +686,7 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
         if (nt >= (1ull << 24)) return fail(PM_ERANGE, "query '%s' has %llu k-mers; this build supports < 2^24 per query",
                                             cur_hdr.c_str(), (unsigned long long)nt);
         q->headers.push_back(cur_hdr);
+        q->headerless.push_back(have_any ? 0 : 1);
         q->n_terms.push_back((uint32_t)nt);
         seq_off.push_back(seqs.size());
         seqs += cur_seq;
@@ -706,7 +708,6 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
             cur_seq.append(line, ll);
         }
     }
-    (void)have_any;
     if (rc == PM_OK) rc = flush();
     if (rc != PM_OK) { delete q; return rc; }
 
@@ -1149,7 +1150,10 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
         while (e < mine.size() && mine[e].query == qi) ++e;
         size_t total = e - p;
         if (p < e && mine[p].doc == PM_DOC_COUNT) { total = mine[p].score; ++p; }   // pruned on the GPU
-        out.push_back('*'); out += q->headers[qi];
+        if (!q->headerless[qi]) out.push_back('*');
+        else if (nb_best >= 0)      // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
+            return fail(PM_EINVAL, "record %zu has sequence lines before any FASTA header: the post-filter cannot parse its result", qi);
+        out += q->headers[qi];
         append_tab_uint_nl(out, total);
         uint32_t min_kmers = 0;
         for (size_t i = p; i < e; ++i) {

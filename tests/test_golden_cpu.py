@@ -390,3 +390,34 @@ def test_product_header_reader_classic_and_compact(oracle):
     with pytest.raises(pm.PMError) as e:
         pm.Index.load_mem(idx)               # the matrix needs the GPU
     assert e.value.code == -2
+
+
+# ---------------- FASTA record rules: product parser vs oracle record loop (property test)
+def test_fasta_record_rules_property(oracle):
+    from hypothesis import given, settings, strategies as st
+    from phylign_amd import _lib as pm
+    k = 5
+    names = ["a_X"]
+    index = oracle.make_index(k, 1, 7, 1, names)          # all-zero matrix: nothing ever matches at t > 0
+    ix = pm.Index.from_names(names, term_size=k)
+    header = st.builds(lambda c, t: c + t, st.sampled_from(">;"), st.text(alphabet="abcXYZ 09_|\t*>;", max_size=12))
+    seqline = st.text(alphabet="ACGT", min_size=0, max_size=14)
+    line = st.one_of(header, seqline, st.just(""), seqline.map(lambda s: s + "N"))
+    text = st.builds(lambda ls, nl: "\n".join(ls) + ("\n" if nl else ""), st.lists(line, max_size=12), st.booleans())
+
+    @settings(max_examples=400, deadline=None)
+    @given(text)
+    def check(fa):
+        data = fa.encode()
+        try:
+            exp = oracle.query_file(index, data, 0.7)
+        except RuntimeError:
+            exp = None
+        try:
+            q = pm.Queries(data, term_size=k)
+            got = pm.format_hits(ix, q, np.zeros(0, dtype=pm.HIT_DTYPE), slot=0)
+        except pm.PMError as e:
+            assert e.code == -6
+            got = None
+        assert got == exp, fa
+    check()

@@ -80,17 +80,18 @@ def main(argv=None):
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
     args = ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
     from . import _lib as pm
-    from .dist import gather_hits
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("PHYLIGN_DIST_BACKEND", "nccl")
-    if os.environ.get("PHYLIGN_SHARE_GPU"):                         # functional tests: several ranks, one GPU
-        local_rank %= max(torch.cuda.device_count(), 1)
+    if world > 1:                                                   # torch only for the multi-rank exchange
+        import torch
+        import torch.distributed as dist
+        from .dist import gather_hits
+        if os.environ.get("PHYLIGN_SHARE_GPU"):                     # functional tests: several ranks, one GPU
+            local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -175,16 +176,18 @@ def main(argv=None):
     # ---- 04_filter: gather the pruned records (and names) to rank 0, merge natively
     if args.filter_out:
         local = np.concatenate(kept) if kept else np.zeros(0, dtype=pm.HIT_DTYPE)
-        t = torch.from_numpy(local.view(np.int32).reshape(-1, 4).copy())
-        if world > 1 and backend == "nccl":
-            t = t.cuda()
-        g = gather_hits(t, dst=0)
         all_names = [names_of]
+        allhits = local
         if world > 1:
+            t = torch.from_numpy(local.view(np.int32).reshape(-1, 4).copy())
+            if backend == "nccl":
+                t = t.cuda()
+            g = gather_hits(t, dst=0)
             all_names = [None] * world if rank == 0 else None
             dist.gather_object(names_of, all_names, dst=0)
+            if rank == 0:
+                allhits = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
         if rank == 0:
-            allhits = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
             names = {}
             for d in all_names:
                 names.update(d)

@@ -113,8 +113,6 @@ struct pm_result {
 };
 
 static const int kPlaneClass[4] = {7, 10, 16, 24};
-// experiment switch for kernel variants (PM_SCAN_FLAGS env, read at pm_init)
-static uint32_t g_scan_flags = 0;
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
@@ -137,7 +135,6 @@ extern "C" int pm_init(int device) {
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
     g_ctx.device = device;
     g_ctx.ready = true;
-    if (const char* f = getenv("PM_SCAN_FLAGS")) g_scan_flags = (uint32_t)strtoul(f, nullptr, 0);
     return PM_OK;
 }
 
@@ -972,7 +969,6 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                 const uint32_t qpb = scan_queries_per_block(g.g);
                 a.tiles = (e - b + qpb - 1) / qpb;
                 a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
-                a.flags = g_scan_flags;
                 a.prune_n = nb_best_hits;
                 a.nh = g.nh; a.hits = hb.p; a.hit_count = g_ctx.d_cnt; a.hit_cap = hb.cap;
                 if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)

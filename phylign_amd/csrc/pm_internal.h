@@ -37,7 +37,6 @@ struct ScanArgs {
     const uint32_t* qmap;       // launch-local index -> query id
     uint32_t        nq;         // queries in this launch
     uint32_t        nh;
-    uint32_t        flags;      // bit0: non-temporal row loads (experiment)
     uint32_t        prune_n;    // > 0: keep the n best documents (+ ties) per (query, batch)
     uint4*          hits;       // pm_hit_t records
     unsigned long long* hit_count;

@@ -256,7 +256,6 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
     const uint8_t* base = bd.matrix + boff;
     const u32x4* hp = reinterpret_cast<const u32x4*>(a.hashes + pb * nh * 8);
     const uint64_t S = bd.sig_size, bm = bd.barrett_m;
-    const bool ntl = (a.flags & 1u) != 0;
 
     u32x4 pl[P];
 #pragma unroll
@@ -280,10 +279,8 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = (u32x4)(0u);
-                    if ((uint32_t)i < left) {
-                        const u32x4* rp = reinterpret_cast<const u32x4*>(base + mod_sig(h[i], S, bm) * stride);
-                        v[i] = ntl ? __builtin_nontemporal_load(rp) : *rp;
-                    }
+                    if ((uint32_t)i < left)
+                        v[i] = *reinterpret_cast<const u32x4*>(base + mod_sig(h[i], S, bm) * stride);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = (j == 0) ? v[i] : (x[i] & v[i]);

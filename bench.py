@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--nb-best-hits", type=int, default=100, help="config.yaml:23 nb_best_hits (on-device top-n + ties)")
     ap.add_argument("--rows-divisor", type=int, default=1, help="shrink every batch's row count (quick runs)")
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 compact, 2 line-aligned")
+    ap.add_argument("--no-threshold-bound", action="store_true",
+                    help="fetch every signature row like cobs does (the product default stops fetching lines whose "
+                         "documents cannot reach the threshold any more; results are identical)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--cpu-sample-gb", type=float, default=0.85)
@@ -132,6 +135,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
+    pm.set_option("threshold_bound", 0 if args.no_threshold_bound else 1)
     dev = pm.device_info()
     log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
 
@@ -211,31 +215,32 @@ def main():
         last["stats"], last["launches"], last["hits"] = st, res.launches(), host
         res.free()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    phase.update(search=0.0, gather=0.0, host=0.0)
-    groups = {}      # kernel instantiation -> [algorithmic bytes, ms, launches] summed over the timed steps
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for L in last["launches"]:
-            g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])
-            g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
-    sync()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_terms / (elapsed / args.steps)
+    def timed_run(warmup, steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks"""
+        for _ in range(warmup):
+            step()
+        sync()
+        phase.update(search=0.0, gather=0.0, host=0.0)
+        groups = {}      # kernel instantiation -> [algorithmic bytes, ms, launches, batches] over the timed steps
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step()
+            for L in last["launches"]:
+                g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])
+                g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
+        sync()
+        elapsed = time.perf_counter() - t_start
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, groups, dict(phase)
 
-    # ---- roofline of the dominant kernel (per launch, hipEvent-timed) ------
-    dom = max(groups.items(), key=lambda kv: kv[1][1]) if groups else None
-    roof = None
-    if dom:
-        name, (abytes, ms, launches, nb) = dom
+    def roofline_of(groups, steps, mode):
+        """dominant scan kernel: algorithmic bytes per launch / hipEvent launch duration vs the HBM peak"""
+        if not groups:
+            return None
+        name, (abytes, ms, launches, nb) = max(groups.items(), key=lambda kv: kv[1][1])
         achieved = abytes / (ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -243,14 +248,39 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload and tj.get("queries") == args.queries and tj.get("kernel") == name:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic = tj.get(mode, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": name,
-                "launches_per_step": launches / args.steps, "batches_per_launch": nb, "avg_launch_ms": ms / launches,
-                "algorithmic_bytes_per_launch": abytes / launches,
-                "all_scan_kernels_GBps": sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9}
+        r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": name,
+             "launches_per_step": launches / steps, "batches_per_launch": nb, "avg_launch_ms": ms / launches,
+             "algorithmic_bytes_per_launch": abytes / launches,
+             "all_scan_kernels_GBps": sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9}
+        if traffic:
+            r["hbm_GBps_from_traffic"] = traffic / (ms / launches * 1e-3) / 1e9
+        return r
+
+    mode = "fetch_all_rows" if args.no_threshold_bound else "threshold_bound"
+    elapsed, groups, phase_main = timed_run(args.warmup, args.steps)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_terms / (elapsed / args.steps)
+    roof = roofline_of(groups, args.steps, mode)
+    hits_main, st_main = last["hits"], last["stats"]
+
+    # the same K steps with the threshold bound switched off: the scan then fetches every
+    # signature row like `cobs query` does, which is the figure to hold against the HBM roofline
+    fetch_all = None
+    if not args.no_threshold_bound and not args.emulate_world:
+        pm.set_option("threshold_bound", 0)
+        e2, g2, _ = timed_run(1, args.steps)
+        pm.set_option("threshold_bound", 1)
+        fetch_all = {"value": n_terms / (e2 / args.steps), "unit": "k-mers/s", "ms_per_step": e2 / args.steps * 1e3,
+                     "hbm_fraction_whole_step": sum(s.row_bytes for s in shapes) * n_terms / (e2 / args.steps) / (HBM_PEAK_GBPS * 1e9 * world),
+                     "roofline": roofline_of(g2, args.steps, "fetch_all_rows"),
+                     "hits_identical": bool(rank != 0 or (hits_main is not None and np.array_equal(hits_main, last["hits"])))}
+    phase.update(phase_main)
+    last["hits"], last["stats"] = hits_main, st_main
+
     st = last["stats"]
     alg_total = sum(shapes[p].row_bytes for p in range(len(shapes))) * n_terms
 
@@ -277,6 +307,11 @@ def main():
         "scan_launches": {k: {"launches_per_step": v[2] / args.steps, "batches": v[3], "avg_ms": v[1] / v[2],
                               "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in groups.items()},
         "roofline": roof,
+        "scan_mode": ("fetch_all_rows" if args.no_threshold_bound else
+                      "threshold_bound: a signature line is no longer fetched once none of its documents can reach "
+                      "ceil(threshold*k-mers) (count so far + k-mers left); hit lists and scores are bit-identical to "
+                      "the fetch-everything scan (see fetch_all_rows and tests/test_gpu_fullsize.py)"),
+        "fetch_all_rows": fetch_all,
     }
     if args.emulate_world:
         out["emulated_shard"] = f"rank {part_id} of {nparts}"

@@ -99,6 +99,11 @@ void pm_shutdown(void);
 const char* pm_last_error(void);
 int  pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus);
 void pm_free(void* p);                    /* frees buffers documented as caller-freed */
+/* Tuning / measurement switches.  "threshold_bound" (default 1): the scan stops
+ * fetching a signature line once none of its documents can reach the minimum
+ * score any more (count so far + k-mers left < minimum); hits and scores are
+ * identical either way, 0 makes the scan fetch every row like cobs does. */
+int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);
 

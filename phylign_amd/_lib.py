@@ -55,6 +55,7 @@ SYMBOLS = [
     ("pm_last_error", C.c_char_p, []),
     ("pm_device_info", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     ("pm_free", None, [_P]),
+    ("pm_set_option", C.c_int, [C.c_char_p, C.c_int64]),
     ("pm_threshold_terms", C.c_uint32, [C.c_double, C.c_uint64]),
     ("pm_index_load_file", C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(_P)]),
     ("pm_index_load_fd", C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(_P)]),
@@ -122,6 +123,10 @@ def init(device=0):
     global _inited_device
     _chk(load().pm_init(device))
     _inited_device = device
+
+
+def set_option(name, value):
+    _chk(load().pm_set_option(name.encode(), int(value)))
 
 
 def device_info():

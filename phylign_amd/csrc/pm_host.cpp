@@ -113,6 +113,8 @@ struct pm_result {
 };
 
 static const int kPlaneClass[4] = {7, 10, 16, 24};
+// pm_set_option("threshold_bound"): product default on; off reproduces the fetch-everything scan
+static uint32_t g_threshold_bound = 1;
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
@@ -164,6 +166,12 @@ extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint6
 }
 
 extern "C" void pm_free(void* p) { free(p); }
+
+extern "C" int pm_set_option(const char* name, int64_t value) {
+    if (!name) return fail(PM_EINVAL, "bad argument");
+    if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
+    return fail(PM_EINVAL, "unknown option '%s'", name);
+}
 
 // The ONE place that turns `-t` into a minimum score (cobs counts_to_result):
 // ceil(threshold * num_terms) in IEEE double.  config.yaml:20 -> Snakefile:410.
@@ -970,6 +978,7 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                 a.tiles = (e - b + qpb - 1) / qpb;
                 a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
                 a.prune_n = nb_best_hits;
+                a.bound = g_threshold_bound;
                 a.nh = g.nh; a.hits = hb.p; a.hit_count = g_ctx.d_cnt; a.hit_cap = hb.cap;
                 if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
                     return bail(fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches));

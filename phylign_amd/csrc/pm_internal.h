@@ -38,6 +38,7 @@ struct ScanArgs {
     uint32_t        nq;         // queries in this launch
     uint32_t        nh;
     uint32_t        prune_n;    // > 0: keep the n best documents (+ ties) per (query, batch)
+    uint32_t        bound;      // 1: stop fetching lines whose documents cannot reach thr any more
     uint4*          hits;       // pm_hit_t records
     unsigned long long* hit_count;
     uint64_t        hit_cap;

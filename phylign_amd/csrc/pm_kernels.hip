@@ -261,11 +261,35 @@ __global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
 #pragma unroll
     for (int p = 0; p < P; ++p) pl[p] = (u32x4)(0u);
 
+    // Threshold bound: a document whose count so far plus the k-mers still to come
+    // cannot reach thr is out for good (count + remaining never grows), and the
+    // hits and their scores do not depend on it.  Once every document behind a
+    // 128-byte line is out, that line is not fetched any more; once the whole
+    // wavefront is out, it stops.  (Lanes that share a line: W consecutive lanes.)
+    constexpr int W = G < 8 ? G : 8;
+    bool line_alive = active;
     for (uint32_t b = 0; b < wmax; ++b) {
+        if (a.bound) {
+            const int need = (int)thr - (int)(nt - b * 8u);     // score required now to still reach thr
+            bool alive = line_alive;
+            if (__any(alive && need > 0)) {
+                const uint32_t K = (1u << P) - (uint32_t)(need > 0 ? need : 0);
+                u32x4 cy = (u32x4)(0u);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const u32x4 both = pl[p] & cy, any = pl[p] | cy;
+                    cy = ((K >> p) & 1u) ? any : both;
+                }
+                if (need > 0) alive = alive && ((cy.x | cy.y | cy.z | cy.w) != 0u) && (uint32_t)need <= nt;
+            }
+            const unsigned long long bal = __ballot(alive);
+            line_alive = ((bal >> (lane & ~(W - 1))) & ((1ull << W) - 1ull)) != 0ull;
+            if (!__any(line_alive && b < nblk)) break;
+        }
         u32x4 x[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = (u32x4)(0u);
-        if (b < nblk) {
+        if (b < nblk && line_alive) {
             const uint32_t left = nt - b * 8u;        // >= 1 valid terms in this block
             for (uint32_t j = 0; j < nh; ++j) {
                 const u32x4* hj = hp + (size_t)(b * nh + j) * 4;

@@ -297,3 +297,25 @@ def test_compact_index_text_bit_exact(pm, oracle, page, n_docs, sigs, nhs, tmp_p
     q = pm.Queries(fasta)
     st = pm.search([ix], q, 0.7).stats
     assert st.algorithmic_bytes == 14 * 120 * sum(nh * page for nh in nhs)
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.1, 0.5, 0.7, 0.9, 1.0])
+def test_threshold_bound_never_changes_results(pm, oracle, thr):
+    """the scan stops fetching lines whose documents cannot reach the minimum score any more:
+    records (hits, scores, count records) must equal the fetch-everything scan and the oracle"""
+    rng = np.random.default_rng(int(thr * 100))
+    lens = [150] * 30 + [31, 38, 39, 40, 47, 250, 1100]
+    queries = [(f"b{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
+    for n_docs, S in ((664, 30000), (4000, 8000), (100, 20000), (9001, 2000)):
+        plant = [(qi, int(rng.integers(0, n_docs)), fr) for qi in range(0, len(lens), 2)
+                 for fr in (1.0, 0.95, 0.72, 0.7, 0.69, 0.5, 0.3, 0.1)]
+        index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant)
+        ix = pm.Index.load_mem(index)
+        q = pm.Queries(fasta)
+        out = {}
+        for mode in (1, 0):
+            pm.set_option("threshold_bound", mode)
+            out[mode] = (pm.search([ix], q, thr).hits(), pm.search([ix], q, thr, nb_best_hits=3).hits())
+        pm.set_option("threshold_bound", 1)
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        assert pm.format_hits(ix, q, out[1][0], slot=0) == oracle.query_file(index, fasta, thr)

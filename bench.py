@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-threshold-bound", action="store_true",
                     help="fetch every signature row like cobs does (the product default stops fetching lines whose "
                          "documents cannot reach the threshold any more; results are identical)")
+    ap.add_argument("--skip-fetch-all", action="store_true", help="do not append the comparison pass with the bound off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--cpu-sample-gb", type=float, default=0.85)
@@ -270,7 +271,7 @@ def main():
     # the same K steps with the threshold bound switched off: the scan then fetches every
     # signature row like `cobs query` does, which is the figure to hold against the HBM roofline
     fetch_all = None
-    if not args.no_threshold_bound and not args.emulate_world:
+    if not args.no_threshold_bound and not args.emulate_world and not args.skip_fetch_all:
         pm.set_option("threshold_bound", 0)
         e2, g2, _ = timed_run(1, args.steps)
         pm.set_option("threshold_bound", 1)

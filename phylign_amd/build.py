@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
     for s in SOURCES:
         o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
-               "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+               "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o] + os.environ.get("PM_EXTRA_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -225,8 +225,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 // G lanes cooperate on one query (16 B = 128 documents per lane); a wave holds
 // 64/G queries; P = number of counter bit planes (queries with < 2^P terms).
+#ifndef PM_SCAN_MIN_WAVES
+#define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
+#endif
 template <int G, int P, bool NH1>
-__global__ __launch_bounds__(256) void k_scan(const ScanArgs a)
+__global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs a)
 {
     constexpr int QPW = 64 / G;
     const int lane = threadIdx.x & 63;

@@ -186,7 +186,6 @@ def main():
     last = {}
     pg_dev = "cuda" if backend == "nccl" else "cpu"
     packed = PackedGather(1 << 16, pg_dev)          # 64 Ki records (1 MiB) per rank in one collective
-    stage = torch.zeros((1 << 16, 4), dtype=torch.int32, device="cuda")   # used when the gather runs on CPU tensors
 
     phase = {"search": 0.0, "gather": 0.0, "host": 0.0}
 
@@ -194,25 +193,25 @@ def main():
         t_a = time.perf_counter()
         res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
         st = res.stats
-        n_local = int(st.n_hits)
         t_b = time.perf_counter()
-        if n_local <= packed.cap:
-            dst_t = packed.records_view() if pg_dev == "cuda" else stage
-            res.copy_hits_device(dst_t.data_ptr(), n_local)
-            if pg_dev != "cuda":
-                packed.records_view()[:n_local] = stage[:n_local].cpu()
-            g = packed.gather(n_local)
-        else:
-            buf = torch.empty((n_local, 4), dtype=torch.int32, device="cuda")
-            res.copy_hits_device(buf.data_ptr(), n_local)
-            g = packed.gather(n_local, overflow=buf if pg_dev == "cuda" else buf.cpu())
+        # every rank brings its own records to its host and puts them into cobs order there (in
+        # parallel); ranks own disjoint, increasing slot ranges, so the rank-order concatenation
+        # that the gather produces on rank 0 is already globally ordered
+        mine_sorted = res.hits()
+        n_local = len(mine_sorted)
         t_c = time.perf_counter()
-        host = None
-        if rank == 0:
-            host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
-            pm.sort_hits(host)
+        if world == 1:
+            host = mine_sorted
+        else:
+            t = torch.from_numpy(mine_sorted.view(np.int32).reshape(-1, 4))
+            if n_local <= packed.cap:
+                packed.records_view()[:n_local].copy_(t)
+                g = packed.gather(n_local)
+            else:
+                g = packed.gather(n_local, overflow=t.cuda() if pg_dev == "cuda" else t)
+            host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1) if rank == 0 else None
         t_d = time.perf_counter()
-        phase["search"] += t_b - t_a; phase["gather"] += t_c - t_b; phase["host"] += t_d - t_c
+        phase["search"] += t_b - t_a; phase["host"] += t_c - t_b; phase["gather"] += t_d - t_c
         last["stats"], last["launches"], last["hits"] = st, res.launches(), host
         res.free()
 

@@ -177,6 +177,9 @@ int  pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size
 int  pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n);
 /* D2D copy of the records into caller-owned device memory (a torch tensor) */
 int  pm_result_copy_hits_device(const pm_result_t* r, void* dst_dptr, uint64_t capacity);
+/* D2H copy into caller-owned host memory (capacity in records), ordered there by
+ * (slot, query, score desc, doc asc) */
+int  pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity);
 /* records on the host ordered by (slot, query, score desc, doc asc);
  * library-owned, valid until pm_result_free */
 int  pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n);

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("pm_hits_sort", None, [_P, C.c_uint64]),
     ("pm_result_hits_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64]),
+    ("pm_result_hits_into", C.c_int, [_P, _P, C.c_uint64]),
     ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_free", None, [_P]),
     ("pm_format_hits", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -302,12 +303,10 @@ class Result:
 
     def hits(self):
         """numpy structured array (HIT_DTYPE) ordered (slot, query, score desc, doc asc)."""
-        p, n = _P(), C.c_uint64()
-        _chk(load().pm_result_hits_host(self._h, C.byref(p), C.byref(n)))
-        if n.value == 0:
-            return np.zeros(0, dtype=HIT_DTYPE)
-        buf = C.string_at(p.value, n.value * HIT_DTYPE.itemsize)
-        return np.frombuffer(buf, dtype=HIT_DTYPE).copy()
+        n = int(self.stats.n_hits)
+        out = np.empty(n, dtype=HIT_DTYPE)
+        _chk(load().pm_result_hits_into(self._h, out.ctypes.data, n))
+        return out
 
     def free(self):
         if self._h:

@@ -1100,6 +1100,19 @@ extern "C" void pm_hits_sort(pm_hit_t* hits, uint64_t n) {
     if (hits && n) order_hits(hits, n);
 }
 
+extern "C" int pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity) {
+    NEED_DEV();
+    if (!r || (!out && r->n_hits)) return fail(PM_EINVAL, "bad argument");
+    if (capacity < r->n_hits) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
+                                          (unsigned long long)capacity, (unsigned long long)r->n_hits);
+    if (r->n_hits) {
+        HIPCHK(hipMemcpyAsync(out, r->d_hits, r->n_hits * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.stream));
+        HIPCHK(hipStreamSynchronize(g_ctx.stream));
+        order_hits(out, r->n_hits);
+    }
+    return PM_OK;
+}
+
 extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {
     NEED_DEV();
     if (!r || !hits || !n) return fail(PM_EINVAL, "bad argument");

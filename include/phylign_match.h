@@ -84,7 +84,7 @@ typedef struct {
 } pm_stats_t;
 
 typedef struct {
-    uint32_t lanes_per_row;      /* template parameter G of k_scan */
+    uint32_t lanes_per_row;      /* template parameter G of k_scan; 0 = the mixed-width launch of the narrow batches */
     uint32_t planes;             /* template parameter P of k_scan */
     uint32_t num_hashes;
     uint32_t n_batches;          /* batch indexes covered by the launch */

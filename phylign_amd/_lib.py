@@ -289,7 +289,7 @@ class Result:
         _chk(load().pm_result_launches(self._h, None, 0, C.byref(n)))
         arr = (Launch * max(n.value, 1))()
         _chk(load().pm_result_launches(self._h, arr, n.value, C.byref(n)))
-        return [{"kernel": f"k_scan<G={a.lanes_per_row},P={a.planes},{'NH1' if a.num_hashes == 1 else 'NHn'}>",
+        return [{"kernel": f"k_scan<G={a.lanes_per_row or 'mixed'},P={a.planes},{'NH1' if a.num_hashes == 1 else 'NHn'}>",
                  "n_batches": a.n_batches, "n_queries": a.n_queries,
                  "algorithmic_bytes": a.algorithmic_bytes, "ms": a.ms} for a in arr[: n.value]]
 

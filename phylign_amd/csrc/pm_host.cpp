@@ -892,17 +892,27 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     // ---- launch plan: one scan launch per (lanes-per-row class, canonicalize,
     // num_hashes) x counter-width class covers every unit of that class;
     // rows wider than 1024 B (column slabs) get a launch of their own.
+    // Narrow rows (fewer than 32 lanes, i.e. at most 256 bytes) of all widths share one
+    // mixed-width launch (g = 0): each of them is short, and separate launches would pay
+    // one drain tail per width class.
     struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; };
     std::vector<Group> groups;
     for (size_t u = 0; u < units.size(); ++u) {
         const pm_index* ix = units[u].ix;
+        const int key = (ix->slabs == 1 && ix->g < 32) ? 0 : ix->g;
         Group* gp = nullptr;
         if (ix->slabs == 1)
             for (auto& g : groups)
-                if (g.slabs == 1 && g.g == ix->g && g.canon == (int)ix->info.canonicalize && g.nh == ix->info.num_hashes) gp = &g;
-        if (!gp) { groups.push_back({ix->g, (int)ix->info.canonicalize, ix->info.num_hashes, ix->slabs, {}}); gp = &groups.back(); }
+                if (g.slabs == 1 && g.g == key && g.canon == (int)ix->info.canonicalize && g.nh == ix->info.num_hashes) gp = &g;
+        if (!gp) { groups.push_back({key, (int)ix->info.canonicalize, ix->info.num_hashes, ix->slabs, {}}); gp = &groups.back(); }
         gp->members.push_back(u);
     }
+    for (auto& g : groups)      // a mixed group with one width is an ordinary group
+        if (g.g == 0) {
+            bool same = true;
+            for (size_t u : g.members) same = same && units[u].ix->g == units[g.members[0]].ix->g;
+            if (same) g.g = units[g.members[0]].ix->g;
+        }
     const size_t n_units = units.size();
     // ---- workspace (persistent, grow-only)
     if (!g_ctx.d_cnt) HIPCHK(hipMalloc((void**)&g_ctx.d_cnt, 8));
@@ -912,7 +922,9 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
         g_ctx.d_desc = nullptr; g_ctx.h_desc = nullptr; g_ctx.desc_cap = 0;
         const size_t cap = std::max<size_t>(n_units, 64);
         HIPCHK(hipMalloc((void**)&g_ctx.d_desc, cap * sizeof(BatchDesc)));
-        HIPCHK(hipHostMalloc((void**)&g_ctx.h_desc, cap * sizeof(BatchDesc), hipHostMallocDefault));
+        // 1 + 4 slices: the base descriptors and one staging slice per query counter-width class
+        // (mixed-width launches patch block ranges per class; a slice is never rewritten within a search)
+        HIPCHK(hipHostMalloc((void**)&g_ctx.h_desc, 5 * cap * sizeof(BatchDesc), hipHostMallocDefault));
         g_ctx.desc_cap = cap;
     }
     {
@@ -924,6 +936,7 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                 d.matrix = ix->d_matrix; d.stride = ix->info.stride; d.sig_size = ix->info.signature_size;
                 d.barrett_m = barrett_m(ix->info.signature_size); d.n_docs = ix->info.n_docs;
                 d.slot = units[u].slot; d.doc_base = units[u].doc_base; d.prune = units[u].prune ? 1u : 0u;
+                d.lanes = (uint32_t)ix->g; d.block_begin = 0; d.pad_ = 0;
             }
         if (n_units)
             HIPCHK(hipMemcpyAsync(g_ctx.d_desc, g_ctx.h_desc, n_units * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
@@ -974,8 +987,25 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                 if (e == b) continue;
                 ScanArgs a;
                 a.batches = g_ctx.d_desc + desc_off; a.n_batches = (uint32_t)g.members.size();
-                const uint32_t qpb = scan_queries_per_block(g.g);
-                a.tiles = (e - b + qpb - 1) / qpb;
+                a.tiles = 0; a.total_blocks = 0;
+                if (g.g > 0) {
+                    const uint32_t qpb = scan_queries_per_block(g.g);
+                    a.tiles = (e - b + qpb - 1) / qpb;
+                } else {
+                    // mixed widths: per-batch workgroup ranges for this query class go into the descriptors
+                    uint64_t blk = 0;
+                    BatchDesc* stage = g_ctx.h_desc + (size_t)(1 + c) * g_ctx.desc_cap + desc_off;
+                    for (size_t k = 0; k < g.members.size(); ++k) {
+                        stage[k] = g_ctx.h_desc[desc_off + k];
+                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes);
+                        stage[k].block_begin = (uint32_t)blk;
+                        blk += (e - b + qpb - 1) / qpb;
+                    }
+                    if (blk > 0x7FFFFFFFull) return bail(fail(PM_ERANGE, "launch grid too large"));
+                    a.total_blocks = (uint32_t)blk;
+                    SCHK(hipMemcpyAsync(g_ctx.d_desc + desc_off, stage, g.members.size() * sizeof(BatchDesc),
+                                        hipMemcpyHostToDevice, st));
+                }
                 a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
                 a.prune_n = nb_best_hits;
                 a.bound = g_threshold_bound;

@@ -14,7 +14,7 @@ struct QDesc {
     uint32_t seq_lo, seq_hi;   // byte offset of the sequence in the packed buffer
 };
 
-// One resident batch index as the scan kernel sees it (48 B, read through the
+// One resident batch index as the scan kernel sees it (64 B, read through the
 // scalar cache: the batch is uniform per workgroup).
 struct BatchDesc {
     const uint8_t* matrix;      // row r at matrix + r*stride, 16-B aligned
@@ -25,12 +25,16 @@ struct BatchDesc {
     uint32_t slot;
     uint32_t doc_base;          // first document of this unit inside its index (compact sub-indexes)
     uint32_t prune;             // 1: ScanArgs.prune_n applies to this unit
+    uint32_t lanes;             // lanes per row (power of two): read by the mixed-width launch
+    uint32_t block_begin;       // first workgroup of this unit in a mixed-width launch
+    uint64_t pad_;
 };
 
 struct ScanArgs {
     const BatchDesc* batches;   // batches of this launch (same lanes-per-row class)
     uint32_t        n_batches;
     uint32_t        tiles;      // workgroups per batch; blockIdx.x = batch*tiles + tile
+    uint32_t        total_blocks;   // mixed-width launch: sum of the per-batch workgroup counts
     const uint64_t* hashes;     // [blk][hash j][8]
     const QDesc*    qd;
     const uint32_t* thr;        // per query minimum score (0 = keep all)
@@ -48,7 +52,8 @@ struct ScanArgs {
 hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t* blk_query,
                              uint64_t n_slots, uint32_t k, int canon, uint32_t nh,
                              uint64_t* hashes, hipStream_t st);
-// g = lanes per row (1..64 pow2), planes = counter bit planes (7,10,16,24);
+// g = lanes per row (1..64 pow2; 0 = mixed, taken per batch from BatchDesc.lanes),
+// planes = counter bit planes (7,10,16,24);
 // slabs > 1 only with n_batches == 1 (rows wider than 1024 B)
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st);
 uint32_t scan_queries_per_block(int g);

@@ -225,22 +225,37 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 // G lanes cooperate on one query (16 B = 128 documents per lane); a wave holds
 // 64/G queries; P = number of counter bit planes (queries with < 2^P terms).
+// G = 0 instantiates the mixed form: the lane-group width comes from the batch
+// descriptor, so ONE launch covers narrow batches of different widths (their
+// launches are short, so the per-launch drain tail would otherwise add up).
 #ifndef PM_SCAN_MIN_WAVES
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
 template <int G, int P, bool NH1>
 __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs a)
 {
-    constexpr int QPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t batch = blockIdx.x / a.tiles;
-    const uint32_t tile = blockIdx.x - batch * a.tiles;
+    uint32_t batch, tile;
+    if constexpr (G > 0) {
+        batch = blockIdx.x / a.tiles;
+        tile = blockIdx.x - batch * a.tiles;
+    } else {                                          // last batch whose first block is <= blockIdx.x
+        uint32_t lo = 0, hi = a.n_batches;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.batches[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+        }
+        batch = lo;
+        tile = blockIdx.x - a.batches[lo].block_begin;
+    }
     const BatchDesc bd = a.batches[batch];            // uniform: scalar loads
-    const uint32_t li = (tile * 4u + (uint32_t)wave) * QPW + (uint32_t)(lane / G);
-    const uint32_t c = (uint32_t)(lane % G);
+    const uint32_t g = G > 0 ? (uint32_t)G : bd.lanes;               // power of two, 1..64
+    const uint32_t gl = G > 0 ? (uint32_t)__builtin_ctz((unsigned)(G > 0 ? G : 1)) : (uint32_t)__builtin_ctz(bd.lanes);
+    const uint32_t li = (tile * 4u + (uint32_t)wave) * (64u >> gl) + ((uint32_t)lane >> gl);
+    const uint32_t c = (uint32_t)lane & (g - 1u);
     const uint32_t slab = blockIdx.y;
-    const uint64_t boff = ((uint64_t)slab * G + c) * 16;   // byte offset of this lane's chunk
+    const uint64_t boff = ((uint64_t)slab * g + c) * 16;   // byte offset of this lane's chunk
     const bool qv = li < a.nq;
 
     uint32_t q = 0, nt = 0, thr = 0;
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     // hits and their scores do not depend on it.  Once every document behind a
     // 128-byte line is out, that line is not fetched any more; once the whole
     // wavefront is out, it stops.  (Lanes that share a line: W consecutive lanes.)
-    constexpr int W = G < 8 ? G : 8;
+    const uint32_t W = g < 8u ? g : 8u;
     bool line_alive = active;
     for (uint32_t b = 0; b < wmax; ++b) {
         if (a.bound) {
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
                 if (need > 0) alive = alive && ((cy.x | cy.y | cy.z | cy.w) != 0u) && (uint32_t)need <= nt;
             }
             const unsigned long long bal = __ballot(alive);
-            line_alive = ((bal >> (lane & ~(W - 1))) & ((1ull << W) - 1ull)) != 0ull;
+            line_alive = ((bal >> ((uint32_t)lane & ~(W - 1u))) & ((1ull << W) - 1ull)) != 0ull;
             if (!__any(line_alive && b < nblk)) break;
         }
         u32x4 x[8];
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
 
     // ---- a7: score >= thr, bit-sliced: carry-out of score + (2^P - thr).
     // valid-document mask first (row padding, inactive lanes)
-    const uint64_t doc0 = ((uint64_t)slab * G + c) * 128;
+    const uint64_t doc0 = ((uint64_t)slab * g + c) * 128;
     u32x4 valid;
     {
         uint32_t kw[4];
@@ -368,8 +383,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     if (a.prune_n > 0u && bd.prune != 0u && gridDim.y == 1) {
         auto group_count = [&](const u32x4& m) -> uint32_t {
             uint32_t v = (uint32_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+            for (int o = (int)(g >> 1); o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
             return v;
         };
         full_count = group_count(mask);
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
 
 template <int G, int P>
 static hipError_t scan_dispatch_nh(const ScanArgs& a, uint32_t slabs, hipStream_t st) {
-    dim3 grid(a.n_batches * a.tiles, slabs, 1);
+    dim3 grid(G > 0 ? a.n_batches * a.tiles : a.total_blocks, slabs, 1);
     if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true>), grid, dim3(256), 0, st, a);
     else           hipLaunchKernelGGL((k_scan<G, P, false>), grid, dim3(256), 0, st, a);
     return hipGetLastError();
@@ -459,6 +473,7 @@ hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hip
     if (a.nq == 0 || a.n_batches == 0) return hipSuccess;
     if (slabs > 1 && a.n_batches != 1) return hipErrorInvalidValue;
     switch (g) {
+        case 0:  return scan_dispatch_p<0>(a, planes, slabs, st);   // mixed widths: grid = a.total_blocks
         case 1:  return scan_dispatch_p<1>(a, planes, slabs, st);
         case 2:  return scan_dispatch_p<2>(a, planes, slabs, st);
         case 4:  return scan_dispatch_p<4>(a, planes, slabs, st);

@@ -319,3 +319,28 @@ def test_threshold_bound_never_changes_results(pm, oracle, thr):
         pm.set_option("threshold_bound", 1)
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         assert pm.format_hits(ix, q, out[1][0], slot=0) == oracle.query_file(index, fasta, thr)
+
+
+def test_mixed_width_launch_with_every_counter_class(pm, oracle):
+    """several narrow batches of different lane-group widths (one mixed-width launch) x queries of
+    every counter-width class, plus a wide and a column-slab batch, in ONE search"""
+    rng = np.random.default_rng(77)
+    lens = [31, 150, 150, 158, 159, 400, 1054, 1055, 3000, 65566, 150, 40]
+    queries = [(f"w{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
+    shapes = [(13, 900), (100, 700), (200, 800), (300, 600), (664, 900), (1500, 500), (4000, 400), (9001, 300), (50, 1000)]
+    cases = []
+    for n_docs, S in shapes:
+        plant = [(qi, int(rng.integers(0, n_docs)), fr) for qi in range(len(lens)) for fr in (1.0, 0.7, 0.5)]
+        cases.append(build_case(oracle, rng, n_docs, S, queries, plant=plant, density=0.3))
+    fasta = cases[0][1]
+    ixs = [pm.Index.load_mem(c[0]) for c in cases]
+    assert len({ix.info.stride for ix in ixs}) >= 7
+    q = pm.Queries(fasta)
+    for thr in (0.7, 0.3):
+        res = pm.search(ixs, q, thr, slot_base=5)
+        kernels = [L["kernel"] for L in res.launches()]
+        assert any("G=mixed" in k for k in kernels) and any("G=32" in k for k in kernels)
+        assert {k.split("P=")[1].split(",")[0] for k in kernels} == {"7", "10", "16", "24"}
+        hits = res.hits()
+        for s, (index, _, _) in enumerate(cases):
+            assert pm.format_hits(ixs[s], q, hits, slot=5 + s) == oracle.query_file(index, fasta, thr), shapes[s]

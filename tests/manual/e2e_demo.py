@@ -3,7 +3,7 @@
 (195 / 176 / 664 documents, 1.84 GB of signatures) with N synthetic 150-bp reads: writes
 the three batches as real .cobs_classic files (synthetic signatures + planted reads), runs
 phylign_amd.match_stage as a subprocess and prints its per-batch timing, then checks a
-sample of the output against the oracle.  Run on the GPU box: python tools/e2e_demo.py [N]"""
+sample of the output against the oracle.  Run on the GPU box: python tests/manual/e2e_demo.py [N]"""
 import gzip
 import json
 import os
@@ -14,9 +14,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
-from oracle import oracle as O                      # tools/ may use the checker
+from oracle import oracle as O                      # lives under tests/: only tests may use the checker
 from phylign_amd import workload as W, postprocess as P
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000

@@ -9,8 +9,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from oracle import oracle as O          # tools/ may use the checker to write a test file
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from oracle import oracle as O          # lives under tests/: only tests may use the checker to write a test file
 from phylign_amd import _lib as pm
 
 pm.init(0)

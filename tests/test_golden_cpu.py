@@ -244,7 +244,7 @@ def test_threshold_rule_product_equals_oracle(oracle):
 def test_product_never_imports_oracle():
     """the product path must not route through the oracle (or any CPU fallback)"""
     for path in glob.glob(os.path.join(ROOT, "phylign_amd", "**", "*"), recursive=True) + \
-            glob.glob(os.path.join(ROOT, "scripts", "*")):
+            glob.glob(os.path.join(ROOT, "scripts", "*")) + glob.glob(os.path.join(ROOT, "tools", "*")):
         if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
             src = open(path).read()
             assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or path.endswith("build.py"), path

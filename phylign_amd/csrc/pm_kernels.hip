@@ -399,54 +399,54 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     }
     uint32_t mw[4] = {mask.x, mask.y, mask.z, mask.w};
 
-    // pruned (query, batch): one extra record {query, PM_DOC_COUNT, unpruned count, slot}
-    // so the text header can still print the number of documents that passed -t
-    {
-        const unsigned long long bal = __ballot(count_rec);
-        if (bal != 0ull) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            const uint32_t src = (uint32_t)(__ffsll((long long)bal) - 1);
-            unsigned long long basev = 0;
-            if (lane == (int)src) basev = atomicAdd(a.hit_count, (unsigned long long)__popcll(bal));
-            const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, (int)src, 64);
-            const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), (int)src, 64);
-            const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
-            if (count_rec && pos < a.hit_cap) a.hits[pos] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
-        }
-    }
-
-    // ---- compaction: every round each lane with a pending hit pops one bit;
-    // ballot + mbcnt rank the writers, one atomic per wave per round.
+    // ---- compaction.  Each lane counts its records (hits + the count record
+    // {query, PM_DOC_COUNT, unpruned count, slot} of a pruned query, which lets the text
+    // header still print the number of documents that passed -t), the wavefront reserves
+    // ONE range with a single atomicAdd, and every lane writes its records behind its
+    // exclusive prefix.  Prefix: ballot + mbcnt when no lane holds more than one record
+    // (the usual case: hits are rare), a shuffle scan otherwise.
+    const uint32_t cnt = (uint32_t)(__popc(mw[0]) + __popc(mw[1]) + __popc(mw[2]) + __popc(mw[3])) + (count_rec ? 1u : 0u);
+    const unsigned long long any_bal = __ballot(cnt != 0u);
+    if (any_bal != 0ull) {
+        uint32_t excl, total;
+        if (__ballot(cnt > 1u) == 0ull) {
+            excl = __builtin_amdgcn_mbcnt_hi((uint32_t)(any_bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any_bal, 0u));
+            total = (uint32_t)__popcll(any_bal);
+        } else {
+            uint32_t incl = cnt;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        uint32_t m = mw[w];
-        while (true) {
-            const bool has = m != 0u;
-            const unsigned long long bal = __ballot(has);
-            if (bal == 0ull) break;
-            uint32_t doc = 0, score = 0;
-            if (has) {
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            excl = incl - cnt;
+            total = (uint32_t)__shfl((int)incl, 63, 64);
+        }
+        unsigned long long basev = 0;
+        if (lane == 0) basev = atomicAdd(a.hit_count, (unsigned long long)total);
+        const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, 0, 64);
+        const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), 0, 64);
+        uint64_t pos = (((uint64_t)bhi << 32) | blo) + excl;
+        if (count_rec) {
+            if (pos < a.hit_cap) a.hits[pos] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
+            ++pos;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t m = mw[w];
+            while (m != 0u) {
                 const int bit = __ffs((int)m) - 1;
                 m &= m - 1u;
-                doc = bd.doc_base + (uint32_t)(doc0 + 32u * w + (uint32_t)bit);
+                uint32_t score = 0;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const uint32_t word = (w == 0) ? pl[p].x : (w == 1) ? pl[p].y : (w == 2) ? pl[p].z : pl[p].w;
                     score |= ((word >> bit) & 1u) << p;
                 }
+                if (pos < a.hit_cap)
+                    a.hits[pos] = make_uint4(q, bd.doc_base + (uint32_t)(doc0 + 32u * w + (uint32_t)bit), score, bd.slot);
+                ++pos;
             }
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            const uint32_t tot = (uint32_t)__popcll(bal);
-            unsigned long long basev = 0;
-            if (lane == (int)(__ffsll((long long)bal) - 1))
-                basev = atomicAdd(a.hit_count, (unsigned long long)tot);
-            const uint32_t src = (uint32_t)(__ffsll((long long)bal) - 1);
-            const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, (int)src, 64);
-            const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), (int)src, 64);
-            const uint64_t pos = (((uint64_t)bhi << 32) | blo) + rank;
-            if (has && pos < a.hit_cap) a.hits[pos] = make_uint4(q, doc, score, bd.slot);
         }
     }
 }

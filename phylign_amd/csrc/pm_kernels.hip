@@ -228,6 +228,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // G = 0 instantiates the mixed form: the lane-group width comes from the batch
 // descriptor, so ONE launch covers narrow batches of different widths (their
 // launches are short, so the per-launch drain tail would otherwise add up).
+#ifndef PM_SCAN_TERMS
+#define PM_SCAN_TERMS 8              // k-mers (row gathers in flight per lane) per step: 8 or 4
+#endif
 #ifndef PM_SCAN_MIN_WAVES
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     }
     const uint64_t stride = bd.stride;
     const bool active = qv && boff < stride;
-    const uint32_t nblk = active ? (nt + 7u) >> 3 : 0u;
+    const uint32_t nblk = active ? (nt + 7u) >> 3 : 0u;      // 8-slot hash blocks of this query
     const uint32_t wmax = wave_max_u32(nblk);
     const uint32_t nh = NH1 ? 1u : a.nh;
 
@@ -286,9 +289,12 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     // wavefront is out, it stops.  (Lanes that share a line: W consecutive lanes.)
     const uint32_t W = g < 8u ? g : 8u;
     bool line_alive = active;
-    for (uint32_t b = 0; b < wmax; ++b) {
+    constexpr int TS = PM_SCAN_TERMS;                 // k-mers per step: 8 (or 4): loads in flight per lane
+    constexpr uint32_t SPB = 8 / TS;                  // steps per 8-slot hash block
+    for (uint32_t sidx = 0; sidx < wmax * SPB; ++sidx) {
+        const uint32_t b = sidx / SPB, t0i = sidx * TS;           // block, first k-mer of this step
         if (a.bound) {
-            const int need = (int)thr - (int)(nt - b * 8u);     // score required now to still reach thr
+            const int need = (int)thr - (int)(nt - t0i);          // score required now to still reach thr
             bool alive = line_alive;
             if (__any(alive && need > 0)) {
                 const uint32_t K = (1u << P) - (uint32_t)(need > 0 ? need : 0);
@@ -302,46 +308,55 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
             }
             const unsigned long long bal = __ballot(alive);
             line_alive = ((bal >> ((uint32_t)lane & ~(W - 1u))) & ((1ull << W) - 1ull)) != 0ull;
-            if (!__any(line_alive && b < nblk)) break;
+            if (!__any(line_alive && t0i < nt)) break;
         }
-        u32x4 x[8];
+        u32x4 x[TS];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = (u32x4)(0u);
-        if (b < nblk && line_alive) {
-            const uint32_t left = nt - b * 8u;        // >= 1 valid terms in this block
+        for (int i = 0; i < TS; ++i) x[i] = (u32x4)(0u);
+        if (active && t0i < nt && line_alive) {
+            const uint32_t left = nt - t0i;           // >= 1 valid terms in this step
             for (uint32_t j = 0; j < nh; ++j) {
-                const u32x4* hj = hp + (size_t)(b * nh + j) * 4;
-                const u32x4 h0 = hj[0], h1 = hj[1], h2 = hj[2], h3 = hj[3];
-                const uint64_t h[8] = {
-                    ((uint64_t)h0.y << 32) | h0.x, ((uint64_t)h0.w << 32) | h0.z,
-                    ((uint64_t)h1.y << 32) | h1.x, ((uint64_t)h1.w << 32) | h1.z,
-                    ((uint64_t)h2.y << 32) | h2.x, ((uint64_t)h2.w << 32) | h2.z,
-                    ((uint64_t)h3.y << 32) | h3.x, ((uint64_t)h3.w << 32) | h3.z};
-                u32x4 v[8];
+                const u32x4* hj = hp + (size_t)(b * nh + j) * 4 + (sidx % SPB) * (TS / 2);
+                uint64_t h[TS];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < TS / 2; ++i) {
+                    const u32x4 hh = hj[i];
+                    h[2 * i] = ((uint64_t)hh.y << 32) | hh.x;
+                    h[2 * i + 1] = ((uint64_t)hh.w << 32) | hh.z;
+                }
+                u32x4 v[TS];
+#pragma unroll
+                for (int i = 0; i < TS; ++i) {
                     v[i] = (u32x4)(0u);
                     if ((uint32_t)i < left)
                         v[i] = *reinterpret_cast<const u32x4*>(base + mod_sig(h[i], S, bm) * stride);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = (j == 0) ? v[i] : (x[i] & v[i]);
+                for (int i = 0; i < TS; ++i) x[i] = (j == 0) ? v[i] : (x[i] & v[i]);
             }
         }
-        // 8 one-bit inputs -> ones/twos/fours planes + one carry of weight 8
-        u32x4 t0, t1, t2, t3, f0, f1, e0;
+        // TS one-bit inputs -> low planes by carry-save adders + one carry rippling upwards
+        u32x4 t0, t1, f0;
         PM_CSA(pl[0], t0, pl[0], x[0], x[1]);
         PM_CSA(pl[0], t1, pl[0], x[2], x[3]);
         PM_CSA(pl[1], f0, pl[1], t0, t1);
-        PM_CSA(pl[0], t2, pl[0], x[4], x[5]);
-        PM_CSA(pl[0], t3, pl[0], x[6], x[7]);
-        PM_CSA(pl[1], f1, pl[1], t2, t3);
-        PM_CSA(pl[2], e0, pl[2], f0, f1);
+        u32x4 carry = f0;
+        int first = 2;
+        if constexpr (TS == 8) {
+            u32x4 t2, t3, f1, e0;
+            PM_CSA(pl[0], t2, pl[0], x[4], x[5]);
+            PM_CSA(pl[0], t3, pl[0], x[6], x[7]);
+            PM_CSA(pl[1], f1, pl[1], t2, t3);
+            PM_CSA(pl[2], e0, pl[2], f0, f1);
+            carry = e0;
+            first = 3;
+        }
 #pragma unroll
-        for (int p = 3; p < P; ++p) {
-            const u32x4 t = pl[p] & e0;
-            pl[p] ^= e0;
-            e0 = t;
+        for (int p = 2; p < P; ++p) {
+            if (p < first) continue;
+            const u32x4 t = pl[p] & carry;
+            pl[p] ^= carry;
+            carry = t;
         }
     }
 

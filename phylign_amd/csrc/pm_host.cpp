@@ -1103,17 +1103,22 @@ static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
 // (slot, query) run (runs are short: the hits of one query in one batch).
 static void order_hits(pm_hit_t* h, uint64_t n) {
     if (n < 4096) { std::sort(h, h + n, hit_less); return; }
-    uint64_t maxkey = 0;
-    for (uint64_t i = 0; i < n; ++i) maxkey |= ((uint64_t)h[i].slot << 32) | h[i].query;
+    // dense key: slot * (max query + 1) + query, 12-bit digits
+    uint32_t max_slot = 0, max_query = 0;
+    for (uint64_t i = 0; i < n; ++i) { max_slot = std::max(max_slot, h[i].slot); max_query = std::max(max_query, h[i].query); }
+    const uint64_t qspan = (uint64_t)max_query + 1;
+    const uint64_t maxkey = (uint64_t)max_slot * qspan + max_query;      // < 2^64: both are 32-bit
+    auto key = [qspan](const pm_hit_t& r) { return (uint64_t)r.slot * qspan + r.query; };
     std::vector<pm_hit_t> tmp((size_t)n);
     pm_hit_t* src = h; pm_hit_t* dst = tmp.data();
-    std::vector<uint64_t> cnt(1 << 11);
-    for (int shift = 0; shift < 64 && (maxkey >> shift) != 0; shift += 11) {
+    constexpr int DB = 12;
+    std::vector<uint64_t> cnt(1u << DB);
+    for (int shift = 0; shift < 64 && (maxkey >> shift) != 0; shift += DB) {
         std::fill(cnt.begin(), cnt.end(), 0);
-        for (uint64_t i = 0; i < n; ++i) cnt[((((uint64_t)src[i].slot << 32) | src[i].query) >> shift) & 2047]++;
+        for (uint64_t i = 0; i < n; ++i) cnt[(key(src[i]) >> shift) & ((1u << DB) - 1)]++;
         uint64_t sum = 0;
         for (auto& c : cnt) { uint64_t t = c; c = sum; sum += t; }
-        for (uint64_t i = 0; i < n; ++i) dst[cnt[((((uint64_t)src[i].slot << 32) | src[i].query) >> shift) & 2047]++] = src[i];
+        for (uint64_t i = 0; i < n; ++i) dst[cnt[(key(src[i]) >> shift) & ((1u << DB) - 1)]++] = src[i];
         std::swap(src, dst);
     }
     if (src != h) memcpy(h, src, (size_t)n * sizeof(pm_hit_t));

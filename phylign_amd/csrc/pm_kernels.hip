@@ -114,11 +114,14 @@ __device__ __forceinline__ uint64_t xxh64_words(const uint64_t w[4], uint32_t k,
 // One thread per padded term slot.  hashes layout: [8-slot block][hash j][8].
 // The packed sequence buffer is padded by 64 bytes so aligned 8-byte reads
 // around a k-mer never leave the allocation.
+// KC > 0 fixes the k-mer length at compile time (31 for the 661k indexes).
+template <int KC>
 __global__ __launch_bounds__(256) void k_hash_terms(
     const uint8_t* __restrict__ seq, const QDesc* __restrict__ qd,
-    const uint32_t* __restrict__ blk_query, uint64_t n_slots, uint32_t k, int canon,
+    const uint32_t* __restrict__ blk_query, uint64_t n_slots, uint32_t k_rt, int canon,
     uint32_t nh, uint64_t* __restrict__ hashes)
 {
+    const uint32_t k = KC > 0 ? (uint32_t)KC : k_rt;
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const uint64_t blk = s >> 3;
@@ -505,8 +508,12 @@ hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t
                              uint64_t* hashes, hipStream_t st) {
     if (n_slots == 0) return hipSuccess;
     const uint64_t blocks = (n_slots + 255) / 256;
-    hipLaunchKernelGGL(k_hash_terms, dim3((uint32_t)blocks), dim3(256), 0, st,
-                       seq, qd, blk_query, n_slots, k, canon, nh, hashes);
+    if (k == 31)
+        hipLaunchKernelGGL(k_hash_terms<31>, dim3((uint32_t)blocks), dim3(256), 0, st,
+                           seq, qd, blk_query, n_slots, k, canon, nh, hashes);
+    else
+        hipLaunchKernelGGL(k_hash_terms<0>, dim3((uint32_t)blocks), dim3(256), 0, st,
+                           seq, qd, blk_query, n_slots, k, canon, nh, hashes);
     return hipGetLastError();
 }
 

@@ -226,3 +226,41 @@ def test_resident_index_server(pm, oracle, tmp_path):
         except Exception:
             srv.kill()
         srv.wait(timeout=30)
+
+
+def test_resident_index_server_evicts_under_budget(pm, oracle, tmp_path):
+    """LRU under an HBM budget: with room for one index, loading a second one drops the first"""
+    import time
+    from phylign_amd.server import request
+    sock = str(tmp_path / "pm.sock")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    paths, texts = [], []
+    for i in range(2):
+        index, fasta, _ = _case(oracle, seed=50 + i, n_docs=664, S=300000)      # ~38 MB in HBM each
+        p = tmp_path / f"i{i}.cobs_classic"
+        p.write_bytes(bytes(index))
+        paths.append((str(p), len(index), fasta))
+        texts.append(oracle.query_file(index, fasta, 0.7))
+    srv = subprocess.Popen([sys.executable, "-m", "phylign_amd.server", "--socket", sock, "--max-gb", "0.06"],
+                           env=env, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.1)
+        seq = [0, 1, 1, 0]
+        cached = []
+        for i in seq:
+            p, n, fasta = paths[i]
+            h, body = request(sock, {"op": "query", "index": p, "index_size": n, "fasta_len": len(fasta), "threshold": 0.7}, fasta)
+            assert h["ok"] and body == texts[i]
+            cached.append(h["cached"])
+        assert cached == [False, False, True, False]
+        st, _ = request(sock, {"op": "stats"})
+        assert st["resident"] == 1 and st["loads"] == 3
+    finally:
+        try:
+            request(sock, {"op": "shutdown"})
+        except Exception:
+            srv.kill()
+        srv.wait(timeout=30)

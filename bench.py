@@ -288,7 +288,7 @@ def main():
         "metric": "query k-mers matched/sec vs 661k-shaped COBS index",
         "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "u32 bit-sliced (bitwise + popcount-style integer)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {len(shapes)} 661k-shaped batches "
                                f"({sum(s.index_bytes for s in shapes) / 1e9:.1f} GB of signatures, "
                                f"{sum(s.row_bytes for s in shapes)} row bytes per k-mer), "
@@ -307,6 +307,7 @@ def main():
         "scan_launches": {k: {"launches_per_step": v[2] / args.steps, "batches": v[3], "avg_ms": v[1] / v[2],
                               "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in groups.items()},
         "roofline": roof,
+        "arithmetic": "bitwise AND / carry-save adders on u32 words (bit-sliced per-document counters), u64 integer hashing",
         "scan_mode": ("fetch_all_rows" if args.no_threshold_bound else
                       "threshold_bound: a signature line is no longer fetched once none of its documents can reach "
                       "ceil(threshold*k-mers) (count so far + k-mers left); hit lists and scores are bit-identical to "

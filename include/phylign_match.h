@@ -60,10 +60,17 @@ typedef struct {
 } pm_index_info_t;
 
 /* One hit record, 16 bytes; identical in HBM, on the wire (RCCL) and on host.
- * A record with doc == PM_DOC_COUNT is not a hit: it is written once per
- * (query, slot) whose hit list was cut to the n best on the GPU and carries in
- * `score` the number of documents that passed the threshold before the cut (the
- * N that cobs prints in the "*header\tN" line, which postprocess_cobs.py keeps). */
+ * A record with doc == PM_DOC_COUNT is not a hit but a COUNT RECORD: `score` holds
+ * the number of documents of (query, slot) that passed the threshold -- the N that
+ * cobs prints in the "*header\tN" line, which postprocess_cobs.py keeps even when
+ * it drops lines.
+ *   In HBM (pm_result_hits_device) the scan kernel writes one RUN per (query, slot
+ * [, column slab / sub-index]) that has hits: a count record followed by the hits in
+ * cobs' line order (score descending, ties by ascending document index); runs are
+ * in arbitrary order.
+ *   On the host (pm_result_hits_into / _host) runs are ordered by (slot, query) and
+ * a count record is kept only where the hit list was cut to the n best on the GPU
+ * (its count then differs from the number of hit records that follow). */
 #define PM_DOC_COUNT 0xFFFFFFFFu
 typedef struct {
     uint32_t query;   /* index of the FASTA record inside the pm_queries_t */
@@ -74,13 +81,16 @@ typedef struct {
 
 typedef struct {
     uint64_t n_queries, n_terms;     /* FASTA records / k-mers in the query set */
-    uint64_t n_hits;                 /* hits over all slots */
+    uint64_t n_hits;                 /* hit records over all slots (= n_records - n_runs) */
     uint64_t algorithmic_bytes;      /* sum_slots n_terms * num_hashes * row_bytes */
     double   ms_total;               /* hipEvent time: hash + scan kernels */
     double   ms_hash;                /* canonicalise + XXH64 kernel */
     double   ms_scan;                /* sum of scan-kernel launch durations */
     uint32_t n_scan_launches;
     uint32_t reserved;
+    uint64_t n_records;              /* records in HBM: hits + one count record per run */
+    uint64_t n_runs;                 /* (query, slot[, slab]) groups with at least one hit */
+    uint64_t fetched_bytes;          /* option "count_fetched": algorithmic bytes of the row chunks really gathered (0 = not counted) */
 } pm_stats_t;
 
 typedef struct {
@@ -91,6 +101,7 @@ typedef struct {
     uint64_t n_queries;
     uint64_t algorithmic_bytes;  /* sum over its batches and k-mers of num_hashes * row_bytes */
     double   ms;                 /* hipEvent duration on the launch stream */
+    uint64_t fetched_bytes;      /* option "count_fetched": the part of algorithmic_bytes really gathered */
 } pm_launch_t;
 
 /* ---- runtime ---------------------------------------------------------- */
@@ -102,7 +113,9 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
 /* Tuning / measurement switches.  "threshold_bound" (default 1): the scan stops
  * fetching a signature line once none of its documents can reach the minimum
  * score any more (count so far + k-mers left < minimum); hits and scores are
- * identical either way, 0 makes the scan fetch every row like cobs does. */
+ * identical either way, 0 makes the scan fetch every row like cobs does.
+ * "count_fetched" (default 0): the scan also counts the algorithmic bytes of the
+ * row chunks it really gathered (pm_stats_t / pm_launch_t .fetched_bytes). */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);
@@ -138,6 +151,10 @@ int  pm_index_plant(pm_index_t* idx, const uint64_t* rows, const uint32_t* docs,
 int  pm_index_probe_gather(const pm_index_t* idx, uint64_t n_groups, uint64_t lookups_per_group,
                            double* ms, uint64_t* bytes);
 int  pm_index_info(const pm_index_t* idx, pm_index_info_t* info);
+/* GPU that holds the matrix (-1: header-only handle).  HIP's current device is a
+ * per-thread setting; every entry point binds the calling thread to the device of
+ * pm_init() first, so indexes loaded from worker threads land on that GPU too. */
+int  pm_index_device(const pm_index_t* idx, int* device);
 const char* pm_index_doc_name(const pm_index_t* idx, uint32_t doc, size_t* len);
 /* copies the row_bytes logical bytes of one row back to the host (checks) */
 int  pm_index_read_row(const pm_index_t* idx, uint64_t row, void* out);
@@ -168,6 +185,14 @@ int  pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint6
  * added to the slot field (global batch numbering across ranks). */
 int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out);
+/* The same job queued on the GPU without waiting for it: returns as soon as the
+ * kernels are enqueued, so the host can order / format / gather the records of the
+ * previous search meanwhile.  Several searches may be in flight (they run in order);
+ * the index array may be released after the call, the indexes and the query set must
+ * stay alive until the result is waited for.  Every pm_result_* getter waits itself. */
+int  pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+                     double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out);
+int  pm_result_wait(pm_result_t* r);
 int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
 /* the scan-kernel launches of the search (one per row-width class x counter-width
  * class, each covering all batches of the class) with their hipEvent durations;
@@ -177,9 +202,9 @@ int  pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size
 int  pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n);
 /* D2D copy of the records into caller-owned device memory (a torch tensor) */
 int  pm_result_copy_hits_device(const pm_result_t* r, void* dst_dptr, uint64_t capacity);
-/* D2H copy into caller-owned host memory (capacity in records), ordered there by
- * (slot, query, score desc, doc asc) */
-int  pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity);
+/* D2H copy into caller-owned host memory (capacity in records, >= pm_stats_t.n_records),
+ * ordered there by (slot, query, score desc, doc asc); *n_out = records written */
+int  pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity, uint64_t* n_out);
 /* records on the host ordered by (slot, query, score desc, doc asc);
  * library-owned, valid until pm_result_free */
 int  pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n);

@@ -36,13 +36,14 @@ class IndexInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_terms", C.c_uint64), ("n_hits", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("ms_total", C.c_double), ("ms_hash", C.c_double),
-                ("ms_scan", C.c_double), ("n_scan_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("ms_scan", C.c_double), ("n_scan_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("n_records", C.c_uint64), ("n_runs", C.c_uint64), ("fetched_bytes", C.c_uint64)]
 
 
 class Launch(C.Structure):
     _fields_ = [("lanes_per_row", C.c_uint32), ("planes", C.c_uint32), ("num_hashes", C.c_uint32),
                 ("n_batches", C.c_uint32), ("n_queries", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
-                ("ms", C.c_double)]
+                ("ms", C.c_double), ("fetched_bytes", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("doc", "<u4"), ("score", "<u4"), ("slot", "<u4")])
@@ -67,6 +68,7 @@ SYMBOLS = [
     ("pm_index_plant", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("pm_index_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("pm_index_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
+    ("pm_index_device", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("pm_index_doc_name", _P, [_P, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("pm_index_read_row", C.c_int, [_P, C.c_uint64, _P]),
     ("pm_index_free", None, [_P]),
@@ -76,12 +78,14 @@ SYMBOLS = [
     ("pm_queries_free", None, [_P]),
     ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
     ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("pm_search_async", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("pm_result_wait", C.c_int, [_P]),
     ("pm_result_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("pm_result_launches", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pm_hits_sort", None, [_P, C.c_uint64]),
     ("pm_result_hits_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64]),
-    ("pm_result_hits_into", C.c_int, [_P, _P, C.c_uint64]),
+    ("pm_result_hits_into", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_free", None, [_P]),
     ("pm_format_hits", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -124,6 +128,11 @@ def init(device=0):
     global _inited_device
     _chk(load().pm_init(device))
     _inited_device = device
+
+
+def bound_device():
+    """GPU ordinal given to init() (None before)"""
+    return _inited_device
 
 
 def set_option(name, value):
@@ -212,6 +221,13 @@ class Index:
         _chk(load().pm_index_info(self._h, C.byref(i)))
         return i
 
+    @property
+    def device(self):
+        """GPU ordinal that holds the matrix (-1: header-only handle)"""
+        d = C.c_int()
+        _chk(load().pm_index_device(self._h, C.byref(d)))
+        return d.value
+
     def doc_name(self, d):
         n = C.c_size_t()
         p = load().pm_index_doc_name(self._h, d, C.byref(n))
@@ -291,7 +307,8 @@ class Result:
         _chk(load().pm_result_launches(self._h, arr, n.value, C.byref(n)))
         return [{"kernel": f"k_scan<G={a.lanes_per_row or 'mixed'},P={a.planes},{'NH1' if a.num_hashes == 1 else 'NHn'}>",
                  "n_batches": a.n_batches, "n_queries": a.n_queries,
-                 "algorithmic_bytes": a.algorithmic_bytes, "ms": a.ms} for a in arr[: n.value]]
+                 "algorithmic_bytes": a.algorithmic_bytes, "ms": a.ms,
+                 "fetched_bytes": a.fetched_bytes} for a in arr[: n.value]]
 
     def hits_device(self):
         p, n = _P(), C.c_uint64()
@@ -301,12 +318,20 @@ class Result:
     def copy_hits_device(self, dst_ptr, capacity):
         _chk(load().pm_result_copy_hits_device(self._h, dst_ptr, capacity))
 
+    def wait(self):
+        """blocks until the GPU has finished this search (results of search_async)"""
+        _chk(load().pm_result_wait(self._h))
+        return self
+
     def hits(self):
-        """numpy structured array (HIT_DTYPE) ordered (slot, query, score desc, doc asc)."""
-        n = int(self.stats.n_hits)
-        out = np.empty(n, dtype=HIT_DTYPE)
-        _chk(load().pm_result_hits_into(self._h, out.ctypes.data, n))
-        return out
+        """numpy structured array (HIT_DTYPE) ordered (slot, query, score desc, doc asc);
+        a count record (doc == PM_DOC_COUNT) leads the hits of a (query, slot) whose list
+        was cut to the n best on the GPU."""
+        cap = int(self.stats.n_records)
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = C.c_uint64()
+        _chk(load().pm_result_hits_into(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value]
 
     def free(self):
         if self._h:
@@ -325,6 +350,14 @@ def search(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hit
     arr = (_P * len(indexes))(*[ix._h for ix in indexes])
     h = _P()
     _chk(load().pm_search(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
+    return Result(h)
+
+
+def search_async(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hits=0) -> Result:
+    """search() that returns once the kernels are queued; Result.wait() / any getter blocks"""
+    arr = (_P * len(indexes))(*[ix._h for ix in indexes])
+    h = _P()
+    _chk(load().pm_search_async(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
     return Result(h)
 
 

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <unistd.h>
@@ -43,23 +44,47 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 struct HitBuf { uint4* p; uint64_t cap; };
+// Per-search scratch that must stay untouched while the search is in flight (several
+// searches may be queued back to back: pm_search_async): record counters with their pinned
+// mirror, batch descriptors, timing events.  Pooled in the context, grow-only.
+struct Workspace {
+    unsigned long long* d_cnt = nullptr;      // [0] records written, [1] runs
+    unsigned long long* h_cnt = nullptr;      // pinned mirror, filled by an async copy behind the kernels
+    BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr; size_t desc_cap = 0;
+    std::vector<hipEvent_t> events;
+    hipEvent_t done = nullptr;                // recorded behind the counter read-back
+    bool busy = false;
+};
+constexpr uint32_t kFetchShards = 4096;       // counters of the "count_fetched" measurement option
 struct Ctx {
     bool ready = false;
     int device = -1;
-    hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;
-    // persistent search workspace (grow-only; nothing is allocated per search
-    // once warm): hit counter, batch descriptors, timing events, hit buffers
-    unsigned long long* d_cnt = nullptr;
-    BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr; size_t desc_cap = 0;
-    std::vector<hipEvent_t> events;
+    hipStream_t stream = nullptr;             // hash + scan kernels
+    hipStream_t copy_stream = nullptr;        // index upload (H2D + re-stride)
+    hipStream_t d2h_stream = nullptr;         // hit records to the host: never queues behind later kernels
+    std::vector<Workspace*> ws;
     std::vector<HitBuf> free_hits;
+    unsigned long long* d_fetch = nullptr;
+    pm_hit_t* h_stage = nullptr; uint64_t h_stage_cap = 0;   // pinned staging of raw records
 };
 static Ctx g_ctx;
-#define NEED_DEV()                                                                         \
-    do {                                                                                   \
-        if (!g_ctx.ready) return fail(PM_ENODEV, "pm_init() has not succeeded: no GPU bound (there is no CPU fallback)"); \
+// HIP's current device is a per-thread setting that starts at 0: every entry point
+// that allocates, copies or launches binds the CALLING thread to the library's
+// device first, so loader threads of a rank with local_rank != 0 never end up
+// on GPU 0 (phylign_amd/match_stage.py loads indexes from a thread pool).
+static int bind_thread() {
+    if (!g_ctx.ready) return fail(PM_ENODEV, "pm_init() has not succeeded: no GPU bound (there is no CPU fallback)");
+    hipError_t e = hipSetDevice(g_ctx.device);
+    if (e != hipSuccess) return fail(PM_EHIP, "hipSetDevice(%d): %s", g_ctx.device, hipGetErrorString(e));
+    return PM_OK;
+}
+#define NEED_DEV()                                  \
+    do {                                            \
+        int rc_dev_ = bind_thread();                \
+        if (rc_dev_) return rc_dev_;                \
     } while (0)
+// frees from any thread: the owning device must be current for the runtime's bookkeeping
+static inline void bind_thread_quiet() { if (g_ctx.ready) (void)hipSetDevice(g_ctx.device); }
 
 // ------------------------------------------------------------------ objects
 struct pm_index {
@@ -73,6 +98,10 @@ struct pm_index {
     // (signature_size_p, num_hashes_p) that is page_size bytes wide; empty for classic
     std::vector<pm_index*> parts;
     uint64_t page_size = 0;
+    // every document name holds a '_' (the "<random prefix>_<accession>" shape the reference's
+    // post-filter relies on, scripts/postprocess_cobs.py:16-18); false -> the n-best cut is
+    // never taken on the GPU for this index (see enqueue_search)
+    bool names_have_sep = true;
 };
 
 struct pm_queries {
@@ -102,19 +131,11 @@ struct pm_queries {
     uint64_t epoch = 0;
 };
 
-struct pm_result {
-    uint4* d_hits = nullptr;
-    uint64_t cap = 0;
-    uint64_t n_hits = 0;
-    pm_stats_t st{};
-    std::vector<pm_hit_t> host;
-    std::vector<pm_launch_t> launches;
-    bool host_ready = false;
-};
-
 static const int kPlaneClass[4] = {7, 10, 16, 24};
 // pm_set_option("threshold_bound"): product default on; off reproduces the fetch-everything scan
 static uint32_t g_threshold_bound = 1;
+// pm_set_option("count_fetched"): the scan also counts the algorithmic bytes it really gathered
+static uint32_t g_count_fetched = 0;
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
@@ -135,6 +156,7 @@ extern "C" int pm_init(int device) {
     if (g_ctx.ready) pm_shutdown();
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.d2h_stream, hipStreamNonBlocking));
     g_ctx.device = device;
     g_ctx.ready = true;
     return PM_OK;
@@ -142,13 +164,23 @@ extern "C" int pm_init(int device) {
 
 extern "C" void pm_shutdown(void) {
     if (!g_ctx.ready) return;
+    bind_thread_quiet();
+    hipDeviceSynchronize();
     hipStreamDestroy(g_ctx.stream);
     hipStreamDestroy(g_ctx.copy_stream);
-    if (g_ctx.d_cnt) hipFree(g_ctx.d_cnt);
-    if (g_ctx.d_desc) hipFree(g_ctx.d_desc);
-    if (g_ctx.h_desc) hipHostFree(g_ctx.h_desc);
-    for (auto e : g_ctx.events) hipEventDestroy(e);
+    hipStreamDestroy(g_ctx.d2h_stream);
+    for (Workspace* w : g_ctx.ws) {
+        if (w->d_cnt) hipFree(w->d_cnt);
+        if (w->h_cnt) hipHostFree(w->h_cnt);
+        if (w->d_desc) hipFree(w->d_desc);
+        if (w->h_desc) hipHostFree(w->h_desc);
+        for (auto e : w->events) hipEventDestroy(e);
+        if (w->done) hipEventDestroy(w->done);
+        delete w;
+    }
     for (auto& b : g_ctx.free_hits) hipFree(b.p);
+    if (g_ctx.d_fetch) hipFree(g_ctx.d_fetch);
+    if (g_ctx.h_stage) hipHostFree(g_ctx.h_stage);
     g_ctx = Ctx();
 }
 
@@ -170,6 +202,7 @@ extern "C" void pm_free(void* p) { free(p); }
 extern "C" int pm_set_option(const char* name, int64_t value) {
     if (!name) return fail(PM_EINVAL, "bad argument");
     if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
+    if (strcmp(name, "count_fetched") == 0) { g_count_fetched = value ? 1u : 0u; return PM_OK; }
     return fail(PM_EINVAL, "unknown option '%s'", name);
 }
 
@@ -253,6 +286,10 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     if (in.row_bytes == 0) return fail(PM_EFORMAT, "index holds no documents");
     uint64_t sc = stride_compact(in.row_bytes), sa = stride_aligned(in.row_bytes);
     uint64_t stride = sc;
+    // loaders run concurrently (match_stage --loaders): the "does the aligned layout still fit"
+    // question and the allocation that answers it are one critical section
+    static std::mutex alloc_mu;
+    std::lock_guard<std::mutex> alloc_lock(alloc_mu);
     if (layout == PM_LAYOUT_ALIGNED) stride = sa;
     else if (layout == PM_LAYOUT_AUTO) {
         size_t fr = 0, tot = 0;
@@ -282,6 +319,7 @@ static void take_names(pm_index* ix, const uint8_t* b, const ParsedHeader& h) {
         ix->name_off[d] = ix->names_blob.size();
         ix->names_blob.append((const char*)b + o, l);
         ix->names_blob.push_back('\0');
+        if (!memchr(b + o, '_', l)) ix->names_have_sep = false;
         o += l + 1;
     }
     ix->name_off[h.n_docs] = ix->names_blob.size();
@@ -627,6 +665,7 @@ extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_doc
         ix->name_off[d] = ix->names_blob.size();
         ix->names_blob.append(names + o, (size_t)(nl - (names + o)));
         ix->names_blob.push_back('\0');
+        if (!memchr(names + o, '_', (size_t)(nl - (names + o)))) ix->names_have_sep = false;
         o = (size_t)(nl - names) + 1;
     }
     ix->name_off[n_docs] = ix->names_blob.size();
@@ -635,6 +674,7 @@ extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_doc
 }
 extern "C" int pm_index_drop_matrix(pm_index_t* ix) {
     if (!ix) return fail(PM_EINVAL, "bad argument");
+    bind_thread_quiet();
     if (ix->d_matrix) { hipFree(ix->d_matrix); ix->d_matrix = nullptr; }
     for (pm_index* p : ix->parts) pm_index_drop_matrix(p);
     ix->info.has_matrix = 0; ix->info.device_bytes = 0;
@@ -657,8 +697,21 @@ extern "C" int pm_index_read_row(const pm_index_t* ix, uint64_t row, void* out) 
     HIPCHK(hipMemcpy(out, ix->d_matrix + row * ix->info.stride, ix->info.row_bytes, hipMemcpyDeviceToHost));
     return PM_OK;
 }
+// GPU that holds the signature matrix (hipPointerGetAttributes); -1 for header-only handles
+extern "C" int pm_index_device(const pm_index_t* ix, int* device) {
+    if (!ix || !device) return fail(PM_EINVAL, "bad argument");
+    const uint8_t* p = ix->d_matrix;
+    if (!p) for (const pm_index* part : ix->parts) if (part->d_matrix) { p = part->d_matrix; break; }
+    *device = -1;
+    if (!p) return PM_OK;
+    hipPointerAttribute_t at;
+    HIPCHK(hipPointerGetAttributes(&at, p));
+    *device = at.device;
+    return PM_OK;
+}
 extern "C" void pm_index_free(pm_index_t* ix) {
     if (!ix) return;
+    bind_thread_quiet();
     if (ix->d_matrix) hipFree(ix->d_matrix);
     for (pm_index* p : ix->parts) pm_index_free(p);
     delete ix;
@@ -765,6 +818,8 @@ extern "C" int pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_t
 }
 extern "C" void pm_queries_free(pm_queries_t* q) {
     if (!q) return;
+    bind_thread_quiet();
+    if (g_ctx.ready && q->on_device) hipStreamSynchronize(g_ctx.stream);   // a search in flight may still read them
     if (q->d_seq) hipFree(q->d_seq);
     if (q->d_qd) hipFree(q->d_qd);
     if (q->d_blkq) hipFree(q->d_blkq);
@@ -834,54 +889,113 @@ extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_has
 }
 
 // ------------------------------------------------------------------- search
-static int get_event(size_t i, hipEvent_t* ev) {
-    while (g_ctx.events.size() <= i) {
+static std::mutex g_pool_mu;            // workspace / hit-buffer pools (searches may come from several threads)
+
+static Workspace* take_workspace() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (Workspace* w : g_ctx.ws) if (!w->busy) { w->busy = true; return w; }
+    Workspace* w = new Workspace();
+    w->busy = true;
+    g_ctx.ws.push_back(w);
+    return w;
+}
+static void give_workspace(Workspace* w) {
+    if (!w) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    w->busy = false;
+}
+static int ws_event(Workspace* w, size_t i, hipEvent_t* ev) {
+    while (w->events.size() <= i) {
         hipEvent_t e = nullptr;
         HIPCHK(hipEventCreate(&e));
-        g_ctx.events.push_back(e);
+        w->events.push_back(e);
     }
-    *ev = g_ctx.events[i];
+    *ev = w->events[i];
     return PM_OK;
 }
 static int take_hit_buffer(uint64_t cap, HitBuf* out) {
-    for (size_t i = 0; i < g_ctx.free_hits.size(); ++i)
-        if (g_ctx.free_hits[i].cap >= cap) {
-            *out = g_ctx.free_hits[i];
-            g_ctx.free_hits.erase(g_ctx.free_hits.begin() + (long)i);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_ctx.free_hits.size();          // the largest pooled buffer that is big enough
+        for (size_t i = 0; i < g_ctx.free_hits.size(); ++i)
+            if (g_ctx.free_hits[i].cap >= cap && (best == g_ctx.free_hits.size() || g_ctx.free_hits[i].cap > g_ctx.free_hits[best].cap))
+                best = i;
+        if (best != g_ctx.free_hits.size()) {
+            *out = g_ctx.free_hits[best];
+            g_ctx.free_hits.erase(g_ctx.free_hits.begin() + (long)best);
             return PM_OK;
         }
+    }
     out->cap = cap;
     HIPCHK(hipMalloc((void**)&out->p, cap * sizeof(uint4)));
     return PM_OK;
 }
 static void give_hit_buffer(HitBuf b) {
     if (!b.p) return;
-    if (g_ctx.ready && g_ctx.free_hits.size() < 2) g_ctx.free_hits.push_back(b);
-    else hipFree(b.p);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_ctx.ready && g_ctx.free_hits.size() < 3) { g_ctx.free_hits.push_back(b); return; }
+    }
+    hipFree(b.p);
 }
 
-extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
-                         double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
-    NEED_DEV();
-    if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
-    if (!(threshold >= 0.0)) return fail(PM_EINVAL, "threshold must be >= 0");
-    // one scan unit per classic index or per sub-index of a compact index
-    struct Unit { const pm_index* ix; uint32_t slot, doc_base; bool prune; };
+// One scan unit per classic index or per sub-index of a compact index.
+struct Unit { const pm_index* ix; uint32_t slot, doc_base; bool prune; };
+struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; };
+
+struct pm_result {
+    // what was asked (kept for the one re-run after a hit-buffer overflow)
+    std::vector<pm_index_t*> idx;
+    pm_queries* q = nullptr;
+    double threshold = 0;
+    uint32_t nb_best = 0, slot_base = 0;
+    // device output
+    uint4* d_hits = nullptr;
+    uint64_t cap = 0;
+    uint64_t n_records = 0, n_runs = 0;
+    pm_stats_t st{};
+    std::vector<pm_launch_t> launches;
+    // in-flight state
+    Workspace* ws = nullptr;
+    bool pending = false;
+    int attempt = 0;
+    size_t nev = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> lev;
+    unsigned long long* h_fetch = nullptr;       // pinned [launch][kFetchShards] when "count_fetched" is on
+    // host copy
+    std::vector<pm_hit_t> host;
+    bool host_ready = false;
+};
+
+static void result_release(pm_result* r) {
+    give_hit_buffer(HitBuf{r->d_hits, r->cap});
+    r->d_hits = nullptr; r->cap = 0;
+    give_workspace(r->ws); r->ws = nullptr;
+    if (r->h_fetch) { hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
+}
+
+// Enqueues hash + scan launches + the read-back of the record counters on the compute
+// stream; returns without waiting for the GPU.
+static int enqueue_search(pm_result* r, uint64_t want_cap) {
+    pm_queries* q = r->q;
+    const size_t n_idx = r->idx.size();
     std::vector<Unit> units;
     for (size_t s = 0; s < n_idx; ++s) {
-        if (!idx[s]) return fail(PM_EINVAL, "index %zu is null", s);
-        if (idx[s]->info.term_size != q->k)
-            return fail(PM_EINVAL, "index %zu has term_size %u but the queries were parsed for %u", s, idx[s]->info.term_size, q->k);
-        if (idx[s]->parts.empty()) {
-            if (!idx[s]->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
-            units.push_back({idx[s], slot_base + (uint32_t)s, 0u, true});
+        const pm_index* ix = r->idx[s];
+        if (ix->parts.empty()) {
+            if (!ix->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
+            // names without '_' make the reference's post-filter raise on a line it would otherwise
+            // drop (scripts/postprocess_cobs.py:10-18): such an index is cut on the host, where
+            // every document that passed -t is seen, so both ways to prune fail alike
+            units.push_back({ix, r->slot_base + (uint32_t)s, 0u, ix->names_have_sep});
         } else {
             // the n best documents of a compact index span its sub-indexes: cut when formatting
-            for (size_t p = 0; p < idx[s]->parts.size(); ++p) {
-                const pm_index* part = idx[s]->parts[p];
+            for (size_t p = 0; p < ix->parts.size(); ++p) {
+                const pm_index* part = ix->parts[p];
                 if (part->info.n_docs == 0) continue;
                 if (!part->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
-                units.push_back({part, slot_base + (uint32_t)s, (uint32_t)(p * idx[s]->page_size * 8), false});
+                units.push_back({part, r->slot_base + (uint32_t)s, (uint32_t)(p * ix->page_size * 8), false});
             }
         }
     }
@@ -895,7 +1009,6 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     // Narrow rows (fewer than 32 lanes, i.e. at most 256 bytes) of all widths share one
     // mixed-width launch (g = 0): each of them is short, and separate launches would pay
     // one drain tail per width class.
-    struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; };
     std::vector<Group> groups;
     for (size_t u = 0; u < units.size(); ++u) {
         const pm_index* ix = units[u].ix;
@@ -914,177 +1027,254 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
             if (same) g.g = units[g.members[0]].ix->g;
         }
     const size_t n_units = units.size();
-    // ---- workspace (persistent, grow-only)
-    if (!g_ctx.d_cnt) HIPCHK(hipMalloc((void**)&g_ctx.d_cnt, 8));
-    if (g_ctx.desc_cap < n_units) {
-        if (g_ctx.d_desc) hipFree(g_ctx.d_desc);
-        if (g_ctx.h_desc) hipHostFree(g_ctx.h_desc);
-        g_ctx.d_desc = nullptr; g_ctx.h_desc = nullptr; g_ctx.desc_cap = 0;
+
+    // ---- workspace of this search (pooled, grow-only): counters, batch descriptors, events
+    if (!r->ws) r->ws = take_workspace();
+    Workspace* ws = r->ws;
+    if (!ws->d_cnt) {
+        HIPCHK(hipMalloc((void**)&ws->d_cnt, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void**)&ws->h_cnt, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
+    }
+    if (ws->desc_cap < n_units) {
+        if (ws->d_desc) hipFree(ws->d_desc);
+        if (ws->h_desc) hipHostFree(ws->h_desc);
+        ws->d_desc = nullptr; ws->h_desc = nullptr; ws->desc_cap = 0;
         const size_t cap = std::max<size_t>(n_units, 64);
-        HIPCHK(hipMalloc((void**)&g_ctx.d_desc, cap * sizeof(BatchDesc)));
+        HIPCHK(hipMalloc((void**)&ws->d_desc, cap * sizeof(BatchDesc)));
         // 1 + 4 slices: the base descriptors and one staging slice per query counter-width class
         // (mixed-width launches patch block ranges per class; a slice is never rewritten within a search)
-        HIPCHK(hipHostMalloc((void**)&g_ctx.h_desc, 5 * cap * sizeof(BatchDesc), hipHostMallocDefault));
-        g_ctx.desc_cap = cap;
+        HIPCHK(hipHostMalloc((void**)&ws->h_desc, 5 * cap * sizeof(BatchDesc), hipHostMallocDefault));
+        ws->desc_cap = cap;
     }
     {
         size_t o = 0;
         for (auto& g : groups)
             for (size_t u : g.members) {
                 const pm_index* ix = units[u].ix;
-                BatchDesc& d = g_ctx.h_desc[o++];
+                BatchDesc& d = ws->h_desc[o++];
                 d.matrix = ix->d_matrix; d.stride = ix->info.stride; d.sig_size = ix->info.signature_size;
                 d.barrett_m = barrett_m(ix->info.signature_size); d.n_docs = ix->info.n_docs;
                 d.slot = units[u].slot; d.doc_base = units[u].doc_base; d.prune = units[u].prune ? 1u : 0u;
                 d.lanes = (uint32_t)ix->g; d.block_begin = 0; d.pad_ = 0;
             }
         if (n_units)
-            HIPCHK(hipMemcpyAsync(g_ctx.d_desc, g_ctx.h_desc, n_units * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(ws->d_desc, ws->h_desc, n_units * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
     }
     // per-query minimum score, cached on the query set per threshold value
-    if (nq && (!q->d_thr || q->thr_for != threshold)) {
+    if (nq && (!q->d_thr || q->thr_for != r->threshold)) {
         std::vector<uint32_t> thr(nq);
-        for (size_t i = 0; i < nq; ++i) thr[i] = threshold == 0.0 ? 0u : pm_threshold_terms(threshold, q->n_terms[i]);
+        for (size_t i = 0; i < nq; ++i) thr[i] = r->threshold == 0.0 ? 0u : pm_threshold_terms(r->threshold, q->n_terms[i]);
         if (!q->d_thr) HIPCHK(hipMalloc((void**)&q->d_thr, nq * 4));
+        HIPCHK(hipStreamSynchronize(st));                 // an earlier search in flight may still read the old values
         HIPCHK(hipMemcpy(q->d_thr, thr.data(), nq * 4, hipMemcpyHostToDevice));
-        q->thr_for = threshold;
+        q->thr_for = r->threshold;
+    }
+    // measurement option: sharded counters of the algorithmic bytes the scan really gathered
+    size_t n_launch_max = 0;
+    for (auto& g : groups) { (void)g; n_launch_max += 4; }
+    if (g_count_fetched) {
+        if (!g_ctx.d_fetch) HIPCHK(hipMalloc((void**)&g_ctx.d_fetch, kFetchShards * sizeof(unsigned long long)));
+        if (r->h_fetch) { hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
+        HIPCHK(hipHostMalloc((void**)&r->h_fetch, std::max<size_t>(n_launch_max, 1) * kFetchShards * sizeof(unsigned long long), hipHostMallocDefault));
     }
 
-    pm_result* r = new pm_result();
-    r->st.n_queries = nq; r->st.n_terms = q->total_terms;
     HitBuf hb{nullptr, 0};
-    auto bail = [&](int code) { give_hit_buffer(hb); delete r; return code; };
-#define SCHK(expr)                                                                         \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return bail(fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
-    } while (0)
-#define RCHK(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
-
-    uint64_t want_cap = std::max<uint64_t>(1u << 20, (uint64_t)nq * 16);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        RCHK(take_hit_buffer(want_cap, &hb));
-        r->launches.clear();
-        q->epoch++;                       // hashes are part of the job: recomputed by every search
-        size_t nev = 0;
-        hipEvent_t ev0, ev1, ev2;
-        RCHK(get_event(nev++, &ev0)); RCHK(get_event(nev++, &ev1)); RCHK(get_event(nev++, &ev2));
-        SCHK(hipMemsetAsync(g_ctx.d_cnt, 0, 8, st));
-        SCHK(hipEventRecord(ev0, st));
-        uint64_t* d_h = nullptr;
-        for (auto& g : groups) RCHK(ensure_hashes(q, g.canon, g.nh, &d_h));
-        SCHK(hipEventRecord(ev1, st));
-        uint64_t alg = 0;
-        size_t desc_off = 0;
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> lev;
-        for (auto& g : groups) {
-            RCHK(ensure_hashes(q, g.canon, g.nh, &d_h));
-            uint64_t rowsum = 0;
-            for (size_t u : g.members) rowsum += units[u].ix->info.row_bytes;
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
-                if (e == b) continue;
-                ScanArgs a;
-                a.batches = g_ctx.d_desc + desc_off; a.n_batches = (uint32_t)g.members.size();
-                a.tiles = 0; a.total_blocks = 0;
-                if (g.g > 0) {
-                    const uint32_t qpb = scan_queries_per_block(g.g);
-                    a.tiles = (e - b + qpb - 1) / qpb;
-                } else {
-                    // mixed widths: per-batch workgroup ranges for this query class go into the descriptors
-                    uint64_t blk = 0;
-                    BatchDesc* stage = g_ctx.h_desc + (size_t)(1 + c) * g_ctx.desc_cap + desc_off;
-                    for (size_t k = 0; k < g.members.size(); ++k) {
-                        stage[k] = g_ctx.h_desc[desc_off + k];
-                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes);
-                        stage[k].block_begin = (uint32_t)blk;
-                        blk += (e - b + qpb - 1) / qpb;
-                    }
-                    if (blk > 0x7FFFFFFFull) return bail(fail(PM_ERANGE, "launch grid too large"));
-                    a.total_blocks = (uint32_t)blk;
-                    SCHK(hipMemcpyAsync(g_ctx.d_desc + desc_off, stage, g.members.size() * sizeof(BatchDesc),
-                                        hipMemcpyHostToDevice, st));
+    { int rc = take_hit_buffer(want_cap, &hb); if (rc) return rc; }
+    r->d_hits = hb.p; r->cap = hb.cap;
+    r->launches.clear(); r->lev.clear();
+    q->epoch++;                       // hashes are part of the job: recomputed by every search
+    r->nev = 0;
+    { int rc = ws_event(ws, r->nev++, &r->ev0); if (rc) return rc; }
+    { int rc = ws_event(ws, r->nev++, &r->ev1); if (rc) return rc; }
+    { int rc = ws_event(ws, r->nev++, &r->ev2); if (rc) return rc; }
+    HIPCHK(hipMemsetAsync(ws->d_cnt, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(hipEventRecord(r->ev0, st));
+    uint64_t* d_h = nullptr;
+    for (auto& g : groups) { int rc = ensure_hashes(q, g.canon, g.nh, &d_h); if (rc) return rc; }
+    HIPCHK(hipEventRecord(r->ev1, st));
+    uint64_t alg = 0;
+    size_t desc_off = 0;
+    for (auto& g : groups) {
+        { int rc = ensure_hashes(q, g.canon, g.nh, &d_h); if (rc) return rc; }
+        uint64_t rowsum = 0;
+        for (size_t u : g.members) rowsum += units[u].ix->info.row_bytes;
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
+            if (e == b) continue;
+            ScanArgs a;
+            a.batches = ws->d_desc + desc_off; a.n_batches = (uint32_t)g.members.size();
+            a.tiles = 0; a.total_blocks = 0;
+            if (g.g > 0) {
+                const uint32_t qpb = scan_queries_per_block(g.g);
+                a.tiles = (e - b + qpb - 1) / qpb;
+            } else {
+                // mixed widths: per-batch workgroup ranges for this query class go into the descriptors
+                uint64_t blk = 0;
+                BatchDesc* stage = ws->h_desc + (size_t)(1 + c) * ws->desc_cap + desc_off;
+                for (size_t k = 0; k < g.members.size(); ++k) {
+                    stage[k] = ws->h_desc[desc_off + k];
+                    const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes);
+                    stage[k].block_begin = (uint32_t)blk;
+                    blk += (e - b + qpb - 1) / qpb;
                 }
-                a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
-                a.prune_n = nb_best_hits;
-                a.bound = g_threshold_bound;
-                a.nh = g.nh; a.hits = hb.p; a.hit_count = g_ctx.d_cnt; a.hit_cap = hb.cap;
-                if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
-                    return bail(fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches));
-                hipEvent_t es, ee;
-                RCHK(get_event(nev++, &es)); RCHK(get_event(nev++, &ee));
-                SCHK(hipEventRecord(es, st));
-                SCHK(launch_scan(a, g.g, kPlaneClass[c], g.slabs, st));
-                SCHK(hipEventRecord(ee, st));
-                lev.push_back({es, ee});
-                uint64_t terms = 0;
-                for (uint32_t i = b; i < e; ++i) terms += q->n_terms[q->qmap[i]];
-                pm_launch_t L{};
-                L.lanes_per_row = (uint32_t)g.g; L.planes = (uint32_t)kPlaneClass[c]; L.num_hashes = g.nh;
-                L.n_batches = a.n_batches; L.n_queries = e - b;
-                L.algorithmic_bytes = terms * g.nh * rowsum;
-                r->launches.push_back(L);
-                alg += L.algorithmic_bytes;
+                if (blk > 0x7FFFFFFFull) return fail(PM_ERANGE, "launch grid too large");
+                a.total_blocks = (uint32_t)blk;
+                HIPCHK(hipMemcpyAsync(ws->d_desc + desc_off, stage, g.members.size() * sizeof(BatchDesc),
+                                      hipMemcpyHostToDevice, st));
             }
-            desc_off += g.members.size();
+            a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
+            a.prune_n = r->nb_best;
+            a.bound = g_threshold_bound;
+            a.nh = g.nh; a.hits = hb.p; a.hit_count = ws->d_cnt; a.hit_cap = hb.cap;
+            a.fetch_count = g_count_fetched ? g_ctx.d_fetch : nullptr; a.fetch_shards = kFetchShards; a.pad_ = 0;
+            if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
+                return fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches);
+            hipEvent_t es, ee;
+            { int rc = ws_event(ws, r->nev++, &es); if (rc) return rc; }
+            { int rc = ws_event(ws, r->nev++, &ee); if (rc) return rc; }
+            if (a.fetch_count) HIPCHK(hipMemsetAsync(g_ctx.d_fetch, 0, kFetchShards * sizeof(unsigned long long), st));
+            HIPCHK(hipEventRecord(es, st));
+            HIPCHK(launch_scan(a, g.g, kPlaneClass[c], g.slabs, st));
+            HIPCHK(hipEventRecord(ee, st));
+            if (a.fetch_count)
+                HIPCHK(hipMemcpyAsync(r->h_fetch + r->launches.size() * kFetchShards, g_ctx.d_fetch,
+                                      kFetchShards * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            r->lev.push_back({es, ee});
+            uint64_t terms = 0;
+            for (uint32_t i = b; i < e; ++i) terms += q->n_terms[q->qmap[i]];
+            pm_launch_t L{};
+            L.lanes_per_row = (uint32_t)g.g; L.planes = (uint32_t)kPlaneClass[c]; L.num_hashes = g.nh;
+            L.n_batches = a.n_batches; L.n_queries = e - b;
+            L.algorithmic_bytes = terms * g.nh * rowsum;
+            r->launches.push_back(L);
+            alg += L.algorithmic_bytes;
         }
-        SCHK(hipEventRecord(ev2, st));
-        unsigned long long cnt = 0;
-        SCHK(hipMemcpyAsync(&cnt, g_ctx.d_cnt, 8, hipMemcpyDeviceToHost, st));
-        SCHK(hipStreamSynchronize(st));
-        r->st.algorithmic_bytes = alg;
-        r->st.n_scan_launches = (uint32_t)r->launches.size();
-        if (cnt <= hb.cap) {
-            r->n_hits = cnt;
-            float ms = 0;
-            SCHK(hipEventElapsedTime(&ms, ev0, ev2)); r->st.ms_total = ms;
-            SCHK(hipEventElapsedTime(&ms, ev0, ev1)); r->st.ms_hash = ms;
-            double scan = 0;
-            for (size_t i = 0; i < lev.size(); ++i) {
-                SCHK(hipEventElapsedTime(&ms, lev[i].first, lev[i].second));
-                r->launches[i].ms = ms; scan += ms;
-            }
-            r->st.ms_scan = scan;
+        desc_off += g.members.size();
+    }
+    HIPCHK(hipEventRecord(r->ev2, st));
+    HIPCHK(hipMemcpyAsync(ws->h_cnt, ws->d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(ws->done, st));
+    r->st.n_queries = nq; r->st.n_terms = q->total_terms;
+    r->st.algorithmic_bytes = alg;
+    r->st.n_scan_launches = (uint32_t)r->launches.size();
+    r->pending = true;
+    return PM_OK;
+}
+
+extern "C" int pm_result_wait(pm_result_t* r) {
+    if (!r) return fail(PM_EINVAL, "bad argument");
+    if (!r->pending) return PM_OK;
+    NEED_DEV();
+    for (;;) {
+        HIPCHK(hipEventSynchronize(r->ws->done));
+        const unsigned long long cnt = r->ws->h_cnt[0], runs = r->ws->h_cnt[1];
+        if (cnt <= r->cap) {
+            r->n_records = cnt; r->n_runs = runs;
             break;
         }
         // hit buffer too small: grow to the exact count and run the job again
-        if (attempt == 1) return bail(fail(PM_EHIP, "hit count changed between runs"));
-        hipFree(hb.p); hb = HitBuf{nullptr, 0};
-        want_cap = cnt;
+        if (r->attempt >= 1) { r->pending = false; result_release(r); return fail(PM_EHIP, "hit count changed between runs"); }
+        r->attempt++;
+        hipFree(r->d_hits); r->d_hits = nullptr; r->cap = 0;
+        int rc = enqueue_search(r, cnt);
+        if (rc) { r->pending = false; result_release(r); return rc; }
     }
-#undef SCHK
-#undef RCHK
-    r->d_hits = hb.p; r->cap = hb.cap;
-    r->st.n_hits = r->n_hits;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, r->ev0, r->ev2)); r->st.ms_total = ms;
+    HIPCHK(hipEventElapsedTime(&ms, r->ev0, r->ev1)); r->st.ms_hash = ms;
+    double scan = 0;
+    uint64_t fetched = 0;
+    for (size_t i = 0; i < r->lev.size(); ++i) {
+        HIPCHK(hipEventElapsedTime(&ms, r->lev[i].first, r->lev[i].second));
+        r->launches[i].ms = ms; scan += ms;
+        if (r->h_fetch) {
+            uint64_t f = 0;
+            for (uint32_t k = 0; k < kFetchShards; ++k) f += r->h_fetch[i * kFetchShards + k];
+            r->launches[i].fetched_bytes = f; fetched += f;
+        }
+    }
+    r->st.ms_scan = scan;
+    r->st.fetched_bytes = fetched;
+    r->st.n_records = r->n_records; r->st.n_runs = r->n_runs; r->st.n_hits = r->n_records - r->n_runs;
+    r->pending = false;
+    give_workspace(r->ws); r->ws = nullptr;       // events and counters have been read: the next search may take them
+    return PM_OK;
+}
+
+extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+                               double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
+    NEED_DEV();
+    if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
+    if (!(threshold >= 0.0)) return fail(PM_EINVAL, "threshold must be >= 0");
+    for (size_t s = 0; s < n_idx; ++s) {
+        if (!idx[s]) return fail(PM_EINVAL, "index %zu is null", s);
+        if (idx[s]->info.term_size != q->k)
+            return fail(PM_EINVAL, "index %zu has term_size %u but the queries were parsed for %u", s, idx[s]->info.term_size, q->k);
+    }
+    pm_result* r = new pm_result();
+    r->idx.assign(idx, idx + n_idx);
+    r->q = q; r->threshold = threshold; r->nb_best = nb_best_hits; r->slot_base = slot_base;
+    const uint64_t want_cap = std::max<uint64_t>(1u << 20, (uint64_t)q->headers.size() * 16);
+    int rc = enqueue_search(r, want_cap);
+    if (rc) {
+        // whatever was queued before the failure must not outlive its buffers
+        hipStreamSynchronize(g_ctx.stream);
+        result_release(r);
+        delete r;
+        return rc;
+    }
     *out = r;
     return PM_OK;
 }
 
+extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+                         double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
+    pm_result_t* r = nullptr;
+    int rc = pm_search_async(idx, n_idx, q, threshold, nb_best_hits, slot_base, &r);
+    if (rc) return rc;
+    rc = pm_result_wait(r);
+    if (rc) { delete r; return rc; }
+    *out = r;
+    return PM_OK;
+}
+
+#define RESULT_READY(r)                                            \
+    do {                                                           \
+        if ((r)->pending) {                                        \
+            int rc_w_ = pm_result_wait(const_cast<pm_result_t*>(r)); \
+            if (rc_w_) return rc_w_;                               \
+        }                                                          \
+    } while (0)
+
 extern "C" int pm_result_stats(const pm_result_t* r, pm_stats_t* st) {
     if (!r || !st) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
     *st = r->st;
     return PM_OK;
 }
 extern "C" int pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size_t* n) {
     if (!r || !n) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
     *n = r->launches.size();
     if (out) for (size_t i = 0; i < r->launches.size() && i < cap; ++i) out[i] = r->launches[i];
     return PM_OK;
 }
 extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n) {
     if (!r || !dptr || !n) return fail(PM_EINVAL, "bad argument");
-    *dptr = r->d_hits; *n = r->n_hits;
+    RESULT_READY(r);
+    *dptr = r->d_hits; *n = r->n_records;
     return PM_OK;
 }
 extern "C" int pm_result_copy_hits_device(const pm_result_t* r, void* dst, uint64_t capacity) {
     NEED_DEV();
-    if (!r || (!dst && r->n_hits)) return fail(PM_EINVAL, "bad argument");
-    if (capacity < r->n_hits) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
-                                          (unsigned long long)capacity, (unsigned long long)r->n_hits);
-    if (r->n_hits) {
-        HIPCHK(hipMemcpyAsync(dst, r->d_hits, r->n_hits * sizeof(uint4), hipMemcpyDeviceToDevice, g_ctx.stream));
-        HIPCHK(hipStreamSynchronize(g_ctx.stream));
+    if (!r || (!dst && r->n_records)) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
+    if (capacity < r->n_records) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
+                                             (unsigned long long)capacity, (unsigned long long)r->n_records);
+    if (r->n_records) {
+        HIPCHK(hipMemcpyAsync(dst, r->d_hits, r->n_records * sizeof(uint4), hipMemcpyDeviceToDevice, g_ctx.d2h_stream));
+        HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
     }
     return PM_OK;
 }
@@ -1093,7 +1283,7 @@ static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
     if (a.slot != b.slot) return a.slot < b.slot;
     if (a.query != b.query) return a.query < b.query;
     const bool am = a.doc == PM_DOC_COUNT, bm = b.doc == PM_DOC_COUNT;
-    if (am != bm) return am;                              // the count record leads its (slot, query) run
+    if (am != bm) return am;                              // count records lead their (slot, query) run
     if (a.score != b.score) return a.score > b.score;     // score descending
     return a.doc < b.doc;                                 // then document index ascending
 }
@@ -1101,7 +1291,9 @@ static inline bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
 // Orders records by (slot, query, score desc, doc asc).  Large inputs: stable
 // LSD radix passes on the (slot, query) key, then a comparison sort inside each
 // (slot, query) run (runs are short: the hits of one query in one batch).
+// General form, for records in any order (gathered from elsewhere, written by a caller).
 static void order_hits(pm_hit_t* h, uint64_t n) {
+    if (std::is_sorted(h, h + n, hit_less)) return;
     if (n < 4096) { std::sort(h, h + n, hit_less); return; }
     // dense key: slot * (max query + 1) + query, 12-bit digits
     uint32_t max_slot = 0, max_query = 0;
@@ -1135,37 +1327,133 @@ extern "C" void pm_hits_sort(pm_hit_t* hits, uint64_t n) {
     if (hits && n) order_hits(hits, n);
 }
 
-extern "C" int pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity) {
-    NEED_DEV();
-    if (!r || (!out && r->n_hits)) return fail(PM_EINVAL, "bad argument");
-    if (capacity < r->n_hits) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
-                                          (unsigned long long)capacity, (unsigned long long)r->n_hits);
-    if (r->n_hits) {
-        HIPCHK(hipMemcpyAsync(out, r->d_hits, r->n_hits * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.stream));
-        HIPCHK(hipStreamSynchronize(g_ctx.stream));
-        order_hits(out, r->n_hits);
+// Records as k_scan writes them: runs {count record}{hits, best first, ties by document},
+// one per (query, slot[, column slab / sub-index]) with hits, in arbitrary run order.
+// Orders the RUNS by (slot, query) -- the records inside a run are already in cobs' line
+// order -- and copies them out; the count record of a run that was not cut on the GPU
+// carries no information (its count is the run length) and is dropped.  Several runs of
+// one (slot, query) (rows wider than 1024 bytes, compact sub-indexes) are merged.
+// Returns the number of records written to `out` (<= n), or ~0 when `in` is not a
+// sequence of runs (then the caller falls back to order_hits).
+struct RunRef { uint64_t key, begin; uint32_t len, pad; };
+static uint64_t order_runs(const pm_hit_t* in, uint64_t n, pm_hit_t* out) {
+    if (n == 0) return 0;
+    if (in[0].doc != PM_DOC_COUNT) return ~0ull;
+    std::vector<RunRef> dir;
+    uint64_t i = 0;
+    while (i < n) {
+        uint64_t e = i + 1;
+        while (e < n && in[e].doc != PM_DOC_COUNT) ++e;
+        if (e - i - 1 > 0xFFFFFFFFull) return ~0ull;
+        dir.push_back({((uint64_t)in[i].slot << 32) | in[i].query, i, (uint32_t)(e - i - 1), 0u});
+        i = e;
     }
+    // order the directory: 16-bit LSD radix over the digits of the key that vary
+    if (dir.size() < 2048) {
+        std::sort(dir.begin(), dir.end(), [](const RunRef& a, const RunRef& b) { return a.key != b.key ? a.key < b.key : a.begin < b.begin; });
+    } else {
+        uint64_t varies = 0;
+        for (const RunRef& d : dir) varies |= d.key ^ dir[0].key;
+        std::vector<RunRef> tmp(dir.size());
+        std::vector<uint64_t> cnt(1u << 16);
+        RunRef* src = dir.data(); RunRef* dst = tmp.data();
+        for (int shift = 0; shift < 64; shift += 16) {
+            if (((varies >> shift) & 0xFFFFull) == 0) continue;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (size_t k = 0; k < dir.size(); ++k) cnt[(src[k].key >> shift) & 0xFFFFu]++;
+            uint64_t sum = 0;
+            for (auto& c : cnt) { uint64_t t = c; c = sum; sum += t; }
+            for (size_t k = 0; k < dir.size(); ++k) dst[cnt[(src[k].key >> shift) & 0xFFFFu]++] = src[k];
+            std::swap(src, dst);
+        }
+        if (src != dir.data()) memcpy(dir.data(), src, dir.size() * sizeof(RunRef));
+    }
+    uint64_t o = 0;
+    size_t k = 0;
+    while (k < dir.size()) {
+        size_t e = k + 1;
+        while (e < dir.size() && dir[e].key == dir[k].key) ++e;
+        if (e == k + 1) {
+            const RunRef& d = dir[k];
+            if (in[d.begin].score != d.len) out[o++] = in[d.begin];        // cut on the GPU: keep the count
+            memcpy(out + o, in + d.begin + 1, (size_t)d.len * sizeof(pm_hit_t));
+            o += d.len;
+        } else {
+            // several runs of one (slot, query): their hits interleave by score
+            const uint64_t first = o;
+            for (size_t j = k; j < e; ++j) {
+                memcpy(out + o, in + dir[j].begin + 1, (size_t)dir[j].len * sizeof(pm_hit_t));
+                o += dir[j].len;
+            }
+            std::sort(out + first, out + o, hit_less);
+        }
+        k = e;
+    }
+    return o;
+}
+
+// D2H of the raw records into the pinned staging buffer (grow-only), on a stream of its own so
+// that the copy never queues behind the kernels of a later search
+static int fetch_records(const pm_result* r, const pm_hit_t** staged) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_ctx.h_stage_cap < r->n_records) {
+        if (g_ctx.h_stage) hipHostFree(g_ctx.h_stage);
+        g_ctx.h_stage = nullptr; g_ctx.h_stage_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(r->n_records + r->n_records / 4, 1u << 16);
+        HIPCHK(hipHostMalloc((void**)&g_ctx.h_stage, cap * sizeof(pm_hit_t), hipHostMallocDefault));
+        g_ctx.h_stage_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(g_ctx.h_stage, r->d_hits, r->n_records * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.d2h_stream));
+    HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
+    *staged = g_ctx.h_stage;
     return PM_OK;
+}
+static int records_to_host(const pm_result* r, pm_hit_t* out, uint64_t* n_out) {
+    *n_out = 0;
+    if (r->n_records == 0) return PM_OK;
+    const pm_hit_t* staged = nullptr;
+    { int rc = fetch_records(r, &staged); if (rc) return rc; }
+    uint64_t n = order_runs(staged, r->n_records, out);
+    if (n == ~0ull) {                                  // not a run stream: order the records themselves
+        memcpy(out, staged, (size_t)r->n_records * sizeof(pm_hit_t));
+        order_hits(out, r->n_records);
+        n = r->n_records;
+    }
+    *n_out = n;
+    return PM_OK;
+}
+
+extern "C" int pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity, uint64_t* n_out) {
+    NEED_DEV();
+    if (!r || !n_out) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
+    if (!out && r->n_records) return fail(PM_EINVAL, "bad argument");
+    if (capacity < r->n_records) return fail(PM_EINVAL, "destination holds %llu records, need up to %llu",
+                                             (unsigned long long)capacity, (unsigned long long)r->n_records);
+    return records_to_host(r, out, n_out);
 }
 
 extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {
     NEED_DEV();
     if (!r || !hits || !n) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
     if (!r->host_ready) {
-        r->host.resize((size_t)r->n_hits);
-        if (r->n_hits) {
-            HIPCHK(hipMemcpyAsync(r->host.data(), r->d_hits, r->n_hits * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.stream));
-            HIPCHK(hipStreamSynchronize(g_ctx.stream));
-        }
-        order_hits(r->host.data(), r->host.size());
+        r->host.resize((size_t)r->n_records);
+        uint64_t got = 0;
+        int rc = records_to_host(r, r->host.data(), &got);
+        if (rc) return rc;
+        r->host.resize((size_t)got);
         r->host_ready = true;
     }
-    *hits = r->host.data(); *n = r->n_hits;
+    *hits = r->host.data(); *n = r->host.size();
     return PM_OK;
 }
 extern "C" void pm_result_free(pm_result_t* r) {
     if (!r) return;
-    give_hit_buffer(HitBuf{r->d_hits, r->cap});
+    bind_thread_quiet();
+    if (r->pending && r->ws) hipEventSynchronize(r->ws->done);      // the GPU may still write into the buffers
+    result_release(r);
     delete r;
 }
 
@@ -1202,7 +1490,12 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
         size_t e = p;
         while (e < mine.size() && mine[e].query == qi) ++e;
         size_t total = e - p;
-        if (p < e && mine[p].doc == PM_DOC_COUNT) { total = mine[p].score; ++p; }   // pruned on the GPU
+        if (p < e && mine[p].doc == PM_DOC_COUNT) {
+            // count records lead the run: cut on the GPU (one record: the number of documents that
+            // passed -t) or raw device runs of several column slabs / sub-indexes (they add up)
+            total = 0;
+            while (p < e && mine[p].doc == PM_DOC_COUNT) { total += mine[p].score; ++p; }
+        }
         if (!q->headerless[qi]) out.push_back('*');
         else if (nb_best >= 0)      // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
             return fail(PM_EINVAL, "record %zu has sequence lines before any FASTA header: the post-filter cannot parse its result", qi);

@@ -44,8 +44,11 @@ struct ScanArgs {
     uint32_t        prune_n;    // > 0: keep the n best documents (+ ties) per (query, batch)
     uint32_t        bound;      // 1: stop fetching lines whose documents cannot reach thr any more
     uint4*          hits;       // pm_hit_t records
-    unsigned long long* hit_count;
+    unsigned long long* hit_count;  // [0] records written (run headers included), [1] runs
     uint64_t        hit_cap;
+    unsigned long long* fetch_count;   // null, or fetch_shards counters of gathered algorithmic bytes
+    uint32_t        fetch_shards;      // power of two
+    uint32_t        pad_;
 };
 
 // launchers (pm_kernels.hip); all asynchronous on `st`, return hipError_t

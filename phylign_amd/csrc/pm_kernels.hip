@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     // wavefront is out, it stops.  (Lanes that share a line: W consecutive lanes.)
     const uint32_t W = g < 8u ? g : 8u;
     bool line_alive = active;
+    uint32_t nfetch = 0;                              // 16-byte row chunks this lane gathered (measurement option)
     constexpr int TS = PM_SCAN_TERMS;                 // k-mers per step: 8 (or 4): loads in flight per lane
     constexpr uint32_t SPB = 8 / TS;                  // steps per 8-slot hash block
     for (uint32_t sidx = 0; sidx < wmax * SPB; ++sidx) {
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
         for (int i = 0; i < TS; ++i) x[i] = (u32x4)(0u);
         if (active && t0i < nt && line_alive) {
             const uint32_t left = nt - t0i;           // >= 1 valid terms in this step
+            if (a.fetch_count) nfetch += (left < (uint32_t)TS ? left : (uint32_t)TS) * nh;
             for (uint32_t j = 0; j < nh; ++j) {
                 const u32x4* hj = hp + (size_t)(b * nh + j) * 4 + (sidx % SPB) * (TS / 2);
                 uint64_t h[TS];
@@ -392,80 +394,125 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     };
     u32x4 mask = ge_mask(thr);
 
+    // lanes of my (query, batch, slab) group inside the wavefront
+    const uint32_t gfirst = (uint32_t)lane & ~(g - 1u);
+    const unsigned long long gmask = (g >= 64u) ? ~0ull : (((1ull << g) - 1ull) << gfirst);
+    auto group_any = [&](bool v) -> bool { return (__ballot(v) & gmask) != 0ull; };
+    auto popc4 = [](const u32x4& m) -> uint32_t {
+        return (uint32_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
+    };
+    auto group_count = [&](const u32x4& m) -> uint32_t {          // xor-shuffle reduction over the g lanes
+        uint32_t v = popc4(m);
+        for (int o = (int)(g >> 1); o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+        return v;
+    };
+
+    // ---- measurement option: how many row chunks were really gathered (threshold bound on/off).
+    // Bytes are counted the algorithmic way (row padding excluded), one sharded atomic per wavefront.
+    if (a.fetch_count) {
+        const uint64_t rb = ((uint64_t)bd.n_docs + 7u) >> 3;
+        const uint64_t vb = boff >= rb ? 0ull : (rb - boff < 16ull ? rb - boff : 16ull);
+        unsigned long long v = (unsigned long long)nfetch * vb;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t lo_ = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+            const uint32_t hi_ = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+            v += ((unsigned long long)hi_ << 32) | lo_;
+        }
+        if (lane == 0 && v != 0ull)
+            atomicAdd(a.fetch_count + ((blockIdx.x * 4u + (uint32_t)wave) & (a.fetch_shards - 1u)), v);
+    }
+
     // ---- a8 fused: keep the n best documents plus ties with the n-th
     // (scripts/postprocess_cobs.py:31-39): raise the cut to the n-th largest score
-    // when more than n documents passed.  The G lanes of a query reduce their
-    // popcounts by xor-shuffles; the search for the cut is a bisection on the score.
-    bool count_rec = false;          // lane 0 of a pruned query reports the unpruned count
-    uint32_t full_count = 0;
+    // when more than n documents passed.  The search for the cut is a bisection on the score.
+    uint32_t total = group_count(mask);      // documents of this group that will be reported
+    uint32_t full_count = total;             // documents that passed -t (what cobs prints in "*header\tN")
     if (a.prune_n > 0u && bd.prune != 0u && gridDim.y == 1) {
-        auto group_count = [&](const u32x4& m) -> uint32_t {
-            uint32_t v = (uint32_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
-            for (int o = (int)(g >> 1); o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-            return v;
-        };
-        full_count = group_count(mask);
         const bool need = full_count > a.prune_n;
-        count_rec = need && c == 0u;
         uint32_t lo = thr, hi = nt + 1u;                 // count(>= lo) >= n, count(>= hi) < n
         while (__ballot(need && hi - lo > 1u) != 0ull) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             const uint32_t cnt = group_count(ge_mask(mid));
             if (need && hi - lo > 1u) { if (cnt >= a.prune_n) lo = mid; else hi = mid; }
         }
-        if (need) mask = ge_mask(lo);
+        if (__ballot(need) != 0ull) {
+            const u32x4 cut = ge_mask(lo);
+            const uint32_t kept = group_count(cut);
+            if (need) { mask = cut; total = kept; }
+        }
     }
-    uint32_t mw[4] = {mask.x, mask.y, mask.z, mask.w};
+    if (__ballot(total != 0u) == 0ull) return;           // the usual case: nothing to report
 
-    // ---- compaction.  Each lane counts its records (hits + the count record
-    // {query, PM_DOC_COUNT, unpruned count, slot} of a pruned query, which lets the text
-    // header still print the number of documents that passed -t), the wavefront reserves
-    // ONE range with a single atomicAdd, and every lane writes its records behind its
-    // exclusive prefix.  Prefix: ballot + mbcnt when no lane holds more than one record
-    // (the usual case: hits are rare), a shuffle scan otherwise.
-    const uint32_t cnt = (uint32_t)(__popc(mw[0]) + __popc(mw[1]) + __popc(mw[2]) + __popc(mw[3])) + (count_rec ? 1u : 0u);
-    const unsigned long long any_bal = __ballot(cnt != 0u);
-    if (any_bal != 0ull) {
-        uint32_t excl, total;
-        if (__ballot(cnt > 1u) == 0ull) {
-            excl = __builtin_amdgcn_mbcnt_hi((uint32_t)(any_bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any_bal, 0u));
-            total = (uint32_t)__popcll(any_bal);
-        } else {
-            uint32_t incl = cnt;
+    // ---- a7 ordering + compaction.  Every group with hits writes ONE contiguous run
+    //     {query, PM_DOC_COUNT, full_count, slot}   then its hits, best score first, ties by
+    //     ascending document index -- the order of cobs' result lines -- so the host never
+    //     sorts records, it only orders runs.  The wavefront reserves the space of all its
+    //     runs with a single atomicAdd; a run's hits are emitted level by level: the largest
+    //     remaining score is found by walking the bit planes from the top (a group-wide
+    //     ballot per plane), its documents are written in lane/bit order behind a
+    //     ballot + mbcnt prefix (shuffle scan when a lane holds several), then removed.
+    const bool leader = (c == 0u) && total != 0u;
+    const uint32_t recs = leader ? total + 1u : 0u;
+    uint32_t incl = recs;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-                if (lane >= o) incl += t;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
+    const unsigned long long lead_bal = __ballot(leader);
+    unsigned long long basev = 0;
+    if (lane == 0) {
+        basev = atomicAdd(a.hit_count, (unsigned long long)wave_total);
+        atomicAdd(a.hit_count + 1, (unsigned long long)__popcll(lead_bal));
+    }
+    const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, 0, 64);
+    const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), 0, 64);
+    const uint32_t run_off = (uint32_t)__shfl((int)(incl - recs), (int)gfirst, 64);
+    const uint64_t run_base = (((uint64_t)bhi << 32) | blo) + run_off;
+    if (leader && run_base < a.hit_cap) a.hits[run_base] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
+
+    u32x4 R = mask;
+    uint32_t emitted = 0;
+    while (__ballot((R.x | R.y | R.z | R.w) != 0u) != 0ull) {
+        u32x4 M = R;
+        uint32_t s = 0;
+#pragma unroll
+        for (int p = P - 1; p >= 0; --p) {
+            const u32x4 t = M & pl[p];
+            if (group_any((t.x | t.y | t.z | t.w) != 0u)) { M = t; s |= 1u << p; }
+        }
+        const uint32_t cnt = popc4(M);
+        uint32_t excl, lvl;
+        if (__ballot(cnt > 1u) == 0ull) {
+            const unsigned long long b = __ballot(cnt != 0u) & gmask;
+            excl = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            lvl = (uint32_t)__popcll(b);
+        } else {
+            uint32_t in2 = cnt;
+            for (uint32_t o = 1; o < g; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)in2, (int)o, 64);
+                if (c >= o) in2 += t;
             }
-            excl = incl - cnt;
-            total = (uint32_t)__shfl((int)incl, 63, 64);
+            excl = in2 - cnt;
+            lvl = (uint32_t)__shfl((int)in2, (int)(gfirst + g - 1u), 64);
         }
-        unsigned long long basev = 0;
-        if (lane == 0) basev = atomicAdd(a.hit_count, (unsigned long long)total);
-        const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, 0, 64);
-        const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), 0, 64);
-        uint64_t pos = (((uint64_t)bhi << 32) | blo) + excl;
-        if (count_rec) {
-            if (pos < a.hit_cap) a.hits[pos] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
-            ++pos;
-        }
+        uint64_t pos = run_base + 1u + emitted + excl;
+        const uint32_t mw[4] = {M.x, M.y, M.z, M.w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             uint32_t m = mw[w];
             while (m != 0u) {
                 const int bit = __ffs((int)m) - 1;
                 m &= m - 1u;
-                uint32_t score = 0;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const uint32_t word = (w == 0) ? pl[p].x : (w == 1) ? pl[p].y : (w == 2) ? pl[p].z : pl[p].w;
-                    score |= ((word >> bit) & 1u) << p;
-                }
                 if (pos < a.hit_cap)
-                    a.hits[pos] = make_uint4(q, bd.doc_base + (uint32_t)(doc0 + 32u * w + (uint32_t)bit), score, bd.slot);
+                    a.hits[pos] = make_uint4(q, bd.doc_base + (uint32_t)(doc0 + 32u * w + (uint32_t)bit), s, bd.slot);
                 ++pos;
             }
         }
+        emitted += lvl;
+        R = R & ~M;
     }
 }
 

@@ -53,6 +53,31 @@ def lpt(weights, n):
     return [sorted(p) for p in parts]
 
 
+class Admission:
+    """HBM budget for decoded-but-not-yet-searched indexes.  Loaders are admitted strictly in
+    submission order (a ticket counter): the consumer drains batches in that same order and a
+    reservation is only returned after its batch was searched, so a later batch must never hold
+    the budget an earlier one is still waiting for.  A batch larger than the whole budget is
+    admitted once nothing else is resident."""
+
+    def __init__(self, budget):
+        self.budget, self.resident, self.next_ticket = float(budget), 0.0, 0
+        self.cv = threading.Condition()
+
+    def acquire(self, ticket, need):
+        with self.cv:
+            while ticket != self.next_ticket or (self.resident > 0 and self.resident + need > self.budget):
+                self.cv.wait()
+            self.resident += need
+            self.next_ticket += 1
+            self.cv.notify_all()
+
+    def release(self, amount):
+        with self.cv:
+            self.resident = max(0.0, self.resident - amount)
+            self.cv.notify_all()
+
+
 def open_index_stream(cobs_dir, batch):
     """(file object, process or None): the plain index if it was decompressed
     already (Snakefile:364-387), else an xzcat pipe (run_cobs_streaming.sh:27)"""
@@ -115,25 +140,29 @@ def main(argv=None):
     nq, n_terms = queries.count()
 
     budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else 0.6 * pm.device_info()["hbm_free"]
-    lock = threading.Condition()
-    state = {"resident": 0.0}
+    admit = Admission(budget)
 
-    def load(pos):
+    def load(ticket, pos):
         b = batches[pos]
-        need = float(sizes.get(b, 0)) * 1.1
-        with lock:
-            while state["resident"] > 0 and state["resident"] + need > budget:
-                lock.wait()
-            state["resident"] += need
+        # what the loader may allocate at most: the line-aligned layout never needs more than twice
+        # the file's bytes (a 65-byte row becomes 128), plus the two 32 MiB staging chunks
+        need = 2.0 * float(sizes.get(b, 0)) + (128 << 20)
+        admit.acquire(ticket, need)
         t0 = time.time()
-        fobj, proc = open_index_stream(args.cobs_dir, b)
         try:
-            ix = pm.Index.load_fd(fobj.fileno(), size_hint=sizes.get(b, 0))
-        finally:
-            fobj.close()
-            if proc is not None and proc.wait() != 0:
-                raise RuntimeError(f"xzcat failed on batch {b}")
-        return pos, ix, need, time.time() - t0
+            fobj, proc = open_index_stream(args.cobs_dir, b)
+            try:
+                ix = pm.Index.load_fd(fobj.fileno(), size_hint=sizes.get(b, 0))
+            finally:
+                fobj.close()
+                if proc is not None and proc.wait() != 0:
+                    raise RuntimeError(f"xzcat failed on batch {b}")
+        except BaseException:
+            admit.release(need)
+            raise
+        held = float(ix.info.device_bytes)
+        admit.release(need - held)                      # keep only what the matrix really occupies
+        return pos, ix, held, time.time() - t0
 
     writers = ThreadPoolExecutor(max_workers=4)
 
@@ -146,11 +175,13 @@ def main(argv=None):
     kept, names_of, log_rows, pending = [], {}, [], []
     nb = args.nb_best_hits
     with ThreadPoolExecutor(max_workers=max(1, args.loaders)) as pool:
-        futures = [pool.submit(load, pos) for pos in mine]
+        futures = [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
         for fut in futures:
             pos, ix, need, t_load = fut.result()
             b = batches[pos]
             info = ix.info
+            if ix.device != pm.bound_device():
+                raise SystemExit(f"batch {b}: matrix is on GPU {ix.device}, this rank drives GPU {pm.bound_device()}")
             if info.term_size != 31:
                 raise SystemExit(f"batch {b}: term_size {info.term_size} != 31")
             t0 = time.time()
@@ -164,9 +195,7 @@ def main(argv=None):
                 kept.append(hits)
                 names_of[pos] = ix.names()
             ix.free()
-            with lock:
-                state["resident"] -= need
-                lock.notify_all()
+            admit.release(need)
             log_rows.append({"batch": b, "load_s": round(t_load, 3), "gpu_ms": round(ms, 3), "hits": int(len(hits)),
                              "search_and_format_s": round(time.time() - t0, 3)})
     for p in pending:

@@ -106,3 +106,34 @@ def test_workload_queries_and_plant_plan(oracle):
     assert sure == 5 * 4            # fractions 1.0, 0.9, 0.8, 0.7 reach the threshold; 0.65 and 0.6 do not
     for pos, (rows, docs) in plan.items():
         assert rows.max() < shapes[pos].signature_size and docs.max() < shapes[pos].n_docs and len(rows) == len(docs)
+
+
+def test_loader_admission_is_in_submission_order_and_never_deadlocks():
+    """match_stage.Admission: loaders are admitted by ticket, so later batches can never take the
+    budget an earlier batch is waiting for (the consumer drains in submission order)."""
+    import random
+    import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from phylign_amd.match_stage import Admission
+
+    rng = random.Random(5)
+    needs = [rng.choice([1, 2, 3, 9, 40]) for _ in range(60)]      # 40 > budget: admitted alone
+    adm = Admission(budget=10)
+    order, lock = [], threading.Lock()
+
+    def load(ticket):
+        time.sleep(rng.random() * 0.002)
+        adm.acquire(ticket, needs[ticket])
+        with lock:
+            order.append(ticket)
+            assert adm.resident <= 10 or adm.resident == needs[ticket]
+        return ticket
+
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        futs = [pool.submit(load, t) for t in range(len(needs))]
+        for t, f in enumerate(futs):                # the consumer: strictly in submission order
+            assert f.result(timeout=20) == t
+            time.sleep(0.0005)
+            adm.release(needs[t])
+    assert order == sorted(order) and adm.resident == 0

@@ -8,12 +8,28 @@ the CPU (oracle "port") baseline timed beside it.
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the whole hot path (canonicalise + XXH64, row map, row
-gather + bit-sliced count, threshold + compaction, gather of the hit records to
-rank 0 and host ordering) of the query batch over every resident phylogenetic
+gather + bit-sliced count, threshold + on-device ordering and compaction, gather of
+the hit records to rank 0) of the query batch over every resident phylogenetic
 batch index.  Workload (BASELINE.json configs[2], SURVEY.md 8d "config 3"): the
 64 661k-shaped batches that fit one GPU (~213 GB of signatures), 100 000
 synthetic 150-bp queries (120 31-mers each), threshold 0.7.  With N > 1 the same
 64 batches are sharded statically over the ranks (strong scaling).
+
+What is reported where:
+  value / roofline     every signature row of every k-mer is gathered, like `cobs
+                       query` does ("fetch_all_rows"): independent of the data, and
+                       the algorithmic bytes are the bytes the kernel really moves.
+  threshold_bound      the product default: lines whose documents cannot reach the
+                       threshold any more are not fetched (identical results).  Its
+                       speed depends on the data, so it is a secondary figure, and
+                       its roofline uses the bytes really gathered (counted in-kernel).
+  clustered            the same two modes after every query was given a HOME batch in
+                       which about half of the documents match it at 0.6-1.0 of its
+                       k-mers (what phylogenetic batches look like for reads of their
+                       own species): many documents near the threshold, long hit lists.
+Steps are software-pipelined: the kernels of step i+1 are queued before the host
+orders / gathers the records of step i (pm_search_async); all of it is inside the
+timed region.
 """
 import argparse
 import json
@@ -89,13 +105,17 @@ def main():
     ap.add_argument("--nb-best-hits", type=int, default=100, help="config.yaml:23 nb_best_hits (on-device top-n + ties)")
     ap.add_argument("--rows-divisor", type=int, default=1, help="shrink every batch's row count (quick runs)")
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 compact, 2 line-aligned")
-    ap.add_argument("--no-threshold-bound", action="store_true",
-                    help="fetch every signature row like cobs does (the product default stops fetching lines whose "
-                         "documents cannot reach the threshold any more; results are identical)")
-    ap.add_argument("--skip-fetch-all", action="store_true", help="do not append the comparison pass with the bound off")
+    ap.add_argument("--headline", default="fetch_all_rows", choices=["fetch_all_rows", "threshold_bound"],
+                    help="scan mode of `value`/`roofline` (default: every row fetched, like cobs; the other mode is "
+                         "reported beside it)")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="skip the other scan mode, the clustered variant and the fetched-bytes pass (profiling runs)")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the clustered (home batch) variant")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queueing the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
     ap.add_argument("--cpu-sample-gb", type=float, default=0.85)
+    ap.add_argument("--dump-hits", default=None, help="rank 0 saves the ordered hit records of the headline mode (.npy)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: hold only the shard rank --emulate-rank would get in an N-way split "
                          "(estimates the per-rank step time of a strong-scaling run; not a reported number)")
@@ -136,7 +156,6 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
-    pm.set_option("threshold_bound", 0 if args.no_threshold_bound else 1)
     dev = pm.device_info()
     log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
 
@@ -145,13 +164,10 @@ def main():
         shapes = W.scale_shapes(shapes, args.rows_divisor)
     nparts = args.emulate_world if (args.emulate_world and world == 1) else world
     parts = W.assign_batches(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))
-    slot_of = {}     # global slot -> shape position (rank-major numbering)
     base = 0
     bases = []
     for r in range(nparts):
         bases.append(base)
-        for i, pos in enumerate(parts[r]):
-            slot_of[base + i] = pos
         base += len(parts[r])
     part_id = args.emulate_rank if nparts != world else rank
     mine = parts[part_id]
@@ -169,6 +185,8 @@ def main():
     for pos in mine:
         s = shapes[pos]
         ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, 661, layout=args.layout)
+        if ix.device != local_rank:
+            sys.exit(f"rank {rank}: batch {s.batch} landed on GPU {ix.device}, expected {local_rank}")
         if pos in plan:
             ix.plant(*plan[pos])
         indexes.append(ix)
@@ -183,20 +201,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    last = {}
     pg_dev = "cuda" if backend == "nccl" else "cpu"
     packed = PackedGather(1 << 16, pg_dev)          # 64 Ki records (1 MiB) per rank in one collective
+    last = {}
+    phase = {"queue": 0.0, "wait": 0.0, "host": 0.0, "gather": 0.0}
 
-    phase = {"search": 0.0, "gather": 0.0, "host": 0.0}
-
-    def step():
+    def queue_step():
         t_a = time.perf_counter()
-        res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
+        res = pm.search_async(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
+        phase["queue"] += time.perf_counter() - t_a
+        return res
+
+    def finish_step(res, groups=None):
+        t_a = time.perf_counter()
+        res.wait()
         st = res.stats
         t_b = time.perf_counter()
-        # every rank brings its own records to its host and puts them into cobs order there (in
-        # parallel); ranks own disjoint, increasing slot ranges, so the rank-order concatenation
-        # that the gather produces on rank 0 is already globally ordered
+        # every rank brings its own records to its host in cobs order (the kernel wrote each hit list
+        # as an ordered run; the host only orders the runs); ranks own disjoint, increasing slot
+        # ranges, so the rank-order concatenation that the gather produces on rank 0 is globally ordered
         mine_sorted = res.hits()
         n_local = len(mine_sorted)
         t_c = time.perf_counter()
@@ -211,83 +234,162 @@ def main():
                 g = packed.gather(n_local, overflow=t.cuda() if pg_dev == "cuda" else t)
             host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1) if rank == 0 else None
         t_d = time.perf_counter()
-        phase["search"] += t_b - t_a; phase["host"] += t_c - t_b; phase["gather"] += t_d - t_c
-        last["stats"], last["launches"], last["hits"] = st, res.launches(), host
+        phase["wait"] += t_b - t_a; phase["host"] += t_c - t_b; phase["gather"] += t_d - t_c
+        last["stats"], last["hits"] = st, host
+        if groups is not None:
+            for L in res.launches():
+                g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])   # [algorithmic bytes, ms, launches, batches]
+                g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
         res.free()
 
-    def timed_run(warmup, steps):
+    def run_steps(n, groups=None):
+        """n steps; unless --no-pipeline the kernels of step i+1 are queued before step i is finished"""
+        prev = None
+        for _ in range(n):
+            cur = queue_step()
+            if args.no_pipeline:
+                finish_step(cur, groups)
+                continue
+            if prev is not None:
+                finish_step(prev, groups)
+            prev = cur
+        if prev is not None:
+            finish_step(prev, groups)
+
+    def timed_run(bound, warmup, steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks"""
-        for _ in range(warmup):
-            step()
+        pm.set_option("threshold_bound", 1 if bound else 0)
+        run_steps(warmup)
         sync()
-        phase.update(search=0.0, gather=0.0, host=0.0)
+        for k in phase:
+            phase[k] = 0.0
         groups = {}      # kernel instantiation -> [algorithmic bytes, ms, launches, batches] over the timed steps
         t_start = time.perf_counter()
-        for _ in range(steps):
-            step()
-            for L in last["launches"]:
-                g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])
-                g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
+        run_steps(steps, groups)
         sync()
         elapsed = time.perf_counter() - t_start
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, groups, dict(phase)
+        return {"elapsed": elapsed, "groups": groups, "phase": dict(phase), "hits": last["hits"], "stats": last["stats"]}
 
-    def roofline_of(groups, steps, mode):
-        """dominant scan kernel: algorithmic bytes per launch / hipEvent launch duration vs the HBM peak"""
+    def fetched_pass(bound):
+        """one untimed search with the in-kernel counter on: algorithmic bytes really gathered, per kernel"""
+        pm.set_option("threshold_bound", 1 if bound else 0)
+        pm.set_option("count_fetched", 1)
+        res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
+        out = {L["kernel"]: (L["fetched_bytes"], L["algorithmic_bytes"]) for L in res.launches()}
+        res.free()
+        pm.set_option("count_fetched", 0)
+        return out
+
+    def pmc_traffic(name, mode):
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("queries") == args.queries and tj.get("kernel") == name \
+                    and world == 1 and args.rows_divisor == 1:
+                return tj.get(mode, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        return None
+
+    def roofline_of(run, steps, mode, fetched):
+        """dominant scan kernel.  fetch_all_rows: algorithmic bytes per launch / hipEvent launch duration.
+        threshold_bound: the algorithmic bytes of the row chunks really gathered (in-kernel count) instead,
+        with the data-independent figure kept as `algorithmic_equivalent_GBps`."""
+        groups = run["groups"]
         if not groups:
             return None
         name, (abytes, ms, launches, nb) = max(groups.items(), key=lambda kv: kv[1][1])
-        achieved = abytes / (ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("queries") == args.queries and tj.get("kernel") == name:
-                    traffic = tj.get(mode, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_per_launch = abytes / launches
+        moved = alg_per_launch
+        if mode == "threshold_bound":
+            moved = fetched[name][0] if fetched and name in fetched else None
+        achieved = moved / (ms / launches * 1e-3) / 1e9 if moved is not None else None
+        traffic = pmc_traffic(name, mode)
         r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": name,
+             "frac": achieved / HBM_PEAK_GBPS if achieved is not None else None, "traffic": traffic, "kernel": name,
              "launches_per_step": launches / steps, "batches_per_launch": nb, "avg_launch_ms": ms / launches,
-             "algorithmic_bytes_per_launch": abytes / launches,
+             "algorithmic_bytes_per_launch": alg_per_launch,
+             "bytes_gathered_per_launch": moved,
              "all_scan_kernels_GBps": sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9}
+        if mode == "threshold_bound":
+            r["algorithmic_equivalent_GBps"] = alg_per_launch / (ms / launches * 1e-3) / 1e9
+            r["note"] = ("achieved = algorithmic bytes of the row chunks this kernel really gathered (pm_set_option "
+                         "count_fetched) / launch time; algorithmic_equivalent_GBps prices the launch at the bytes a "
+                         "fetch-everything scan would move and may exceed the HBM peak")
         if traffic:
             r["hbm_GBps_from_traffic"] = traffic / (ms / launches * 1e-3) / 1e9
         return r
 
-    mode = "fetch_all_rows" if args.no_threshold_bound else "threshold_bound"
-    elapsed, groups, phase_main = timed_run(args.warmup, args.steps)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_terms / (elapsed / args.steps)
-    roof = roofline_of(groups, args.steps, mode)
-    hits_main, st_main = last["hits"], last["stats"]
+    def summary(run, steps, mode, fetched):
+        el = run["elapsed"] / steps
+        alg_total = sum(s.row_bytes for s in shapes) * n_terms
+        out = {"value": n_terms / el, "unit": "k-mers/s", "ms_per_step": el * 1e3,
+               "hbm_fraction_whole_step_algorithmic": alg_total / el / (HBM_PEAK_GBPS * 1e9 * world),
+               "roofline": roofline_of(run, steps, mode, fetched),
+               "hits": int(len(run["hits"])) if run["hits"] is not None else None}
+        if fetched:
+            tot_f = sum(v[0] for v in fetched.values()); tot_a = sum(v[1] for v in fetched.values())
+            out["fraction_of_row_bytes_gathered_rank0"] = tot_f / tot_a if tot_a else None
+        return out
 
-    # the same K steps with the threshold bound switched off: the scan then fetches every
-    # signature row like `cobs query` does, which is the figure to hold against the HBM roofline
-    fetch_all = None
-    if not args.no_threshold_bound and not args.emulate_world and not args.skip_fetch_all:
-        pm.set_option("threshold_bound", 0)
-        e2, g2, _ = timed_run(1, args.steps)
-        pm.set_option("threshold_bound", 1)
-        fetch_all = {"value": n_terms / (e2 / args.steps), "unit": "k-mers/s", "ms_per_step": e2 / args.steps * 1e3,
-                     "hbm_fraction_whole_step": sum(s.row_bytes for s in shapes) * n_terms / (e2 / args.steps) / (HBM_PEAK_GBPS * 1e9 * world),
-                     "roofline": roofline_of(g2, args.steps, "fetch_all_rows"),
-                     "hits_identical": bool(rank != 0 or (hits_main is not None and np.array_equal(hits_main, last["hits"])))}
-    phase.update(phase_main)
-    last["hits"], last["stats"] = hits_main, st_main
+    modes = ["fetch_all_rows", "threshold_bound"]
+    head = args.headline
+    other = [m for m in modes if m != head][0]
+    full = not (args.only_headline or args.emulate_world)
 
-    st = last["stats"]
-    alg_total = sum(shapes[p].row_bytes for p in range(len(shapes))) * n_terms
+    run_head = timed_run(head == "threshold_bound", args.warmup, args.steps)
+    fetched_head = fetched_pass(head == "threshold_bound") if full or head == "threshold_bound" else None
+    if fetched_head and head == "fetch_all_rows":
+        for k, (f, a) in fetched_head.items():
+            assert f == a, f"{k}: fetch-all scan gathered {f} bytes, algorithmic bytes are {a}"
+    sum_head = summary(run_head, args.steps, head, fetched_head)
+    st_head = run_head["stats"]
 
+    sum_other = None
+    ok = True
+    if full:
+        run_other = timed_run(other == "threshold_bound", 1, args.steps)
+        fetched_other = fetched_pass(other == "threshold_bound")
+        sum_other = summary(run_other, args.steps, other, fetched_other)
+        same = bool(rank != 0 or np.array_equal(run_head["hits"], run_other["hits"]))
+        sum_other["hits_identical_to_headline"] = same
+        sum_other["speed_vs_headline"] = sum_other["value"] / sum_head["value"]
+        ok = ok and same
+
+    # ---- clustered variant: every query gets a home batch (changes the resident matrices: last)
+    clustered = None
+    if full and not args.no_clustered:
+        t0 = time.time()
+        for pos, ix in zip(mine, indexes):
+            ix.plant_cluster(q, pos, len(shapes), seed=97)
+        log(f"[bench] clustered planting {time.time() - t0:.1f}s")
+        c_runs = {}
+        for m in modes:
+            r = timed_run(m == "threshold_bound", 1, args.steps)
+            c_runs[m] = (r, fetched_pass(m == "threshold_bound"))
+        same = bool(rank != 0 or np.array_equal(c_runs[modes[0]][0]["hits"], c_runs[modes[1]][0]["hits"]))
+        ok = ok and same
+        clustered = {
+            "data": ("every query has one home batch (query i -> batch i mod %d) in which about half of the "
+                     "32-document clusters match it at a k-mer fraction of 0.60-1.0 (k_plant_cluster); elsewhere "
+                     "only the Bernoulli(1/4) background" % len(shapes)),
+            "hits_identical": same,
+        }
+        for m in modes:
+            clustered[m] = summary(c_runs[m][0], args.steps, m, c_runs[m][1])
+        clustered["threshold_bound"]["speed_vs_fetch_all_rows"] = (clustered["threshold_bound"]["value"] /
+                                                                   clustered["fetch_all_rows"]["value"])
+    pm.set_option("threshold_bound", 1)
+
+    ph = run_head["phase"]
     out = {
         "metric": "query k-mers matched/sec vs 661k-shaped COBS index",
-        "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "value": sum_head["value"], "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sum_head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {len(shapes)} 661k-shaped batches "
                                f"({sum(s.index_bytes for s in shapes) / 1e9:.1f} GB of signatures, "
@@ -296,39 +398,65 @@ def main():
                    "batches": len(shapes), "queries": nq, "query_len": args.qlen, "k": 31,
                    "num_hashes": 1, "threshold": args.threshold, "nb_best_hits": args.nb_best_hits,
                    "rows_divisor": args.rows_divisor,
-                   "sharding": f"{world} rank(s), static LPT batch assignment, one gather of hit records"},
-        "hbm_fraction_whole_step": alg_total / (elapsed / args.steps) / (HBM_PEAK_GBPS * 1e9 * world),
-        "hits": int(len(last["hits"])) if last["hits"] is not None else None,
+                   "sharding": f"{world} rank(s), static LPT batch assignment, one gather of hit records",
+                   "pipelined_steps": not args.no_pipeline},
+        "scan_mode": (head + (": every signature row of every k-mer is gathered, like `cobs query` does -- independent "
+                              "of the data; the product default (threshold_bound) is reported beside it"
+                              if head == "fetch_all_rows" else
+                              ": a signature line is no longer fetched once none of its documents can reach "
+                              "ceil(threshold*k-mers); identical results, data-dependent speed")),
+        "hbm_fraction_whole_step": sum_head["hbm_fraction_whole_step_algorithmic"],
+        "hits": sum_head["hits"],
         "planted_pairs_at_or_above_threshold": sure_hits,
-        "rank0_ms": {"kernels_total": st.ms_total, "hash": st.ms_hash, "scan": st.ms_scan,
-                     "host_search_call": phase["search"] / args.steps * 1e3,
-                     "host_hit_gather": phase["gather"] / args.steps * 1e3,
-                     "host_d2h_and_order": phase["host"] / args.steps * 1e3},
+        "rank0_ms": {"kernels_total": st_head.ms_total, "hash": st_head.ms_hash, "scan": st_head.ms_scan,
+                     "host_queue_launches": ph["queue"] / args.steps * 1e3,
+                     "host_wait_for_gpu": ph["wait"] / args.steps * 1e3,
+                     "host_d2h_and_run_order": ph["host"] / args.steps * 1e3,
+                     "host_hit_gather": ph["gather"] / args.steps * 1e3},
         "scan_launches": {k: {"launches_per_step": v[2] / args.steps, "batches": v[3], "avg_ms": v[1] / v[2],
-                              "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in groups.items()},
-        "roofline": roof,
+                              "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in run_head["groups"].items()},
+        "roofline": sum_head["roofline"],
         "arithmetic": "bitwise AND / carry-save adders on u32 words (bit-sliced per-document counters), u64 integer hashing",
-        "scan_mode": ("fetch_all_rows" if args.no_threshold_bound else
-                      "threshold_bound: a signature line is no longer fetched once none of its documents can reach "
-                      "ceil(threshold*k-mers) (count so far + k-mers left); hit lists and scores are bit-identical to "
-                      "the fetch-everything scan (see fetch_all_rows and tests/test_gpu_fullsize.py)"),
-        "fetch_all_rows": fetch_all,
+        other: sum_other,
+        "clustered": clustered,
     }
     if args.emulate_world:
         out["emulated_shard"] = f"rank {part_id} of {nparts}"
-    if rank == 0 and not args.emulate_world and last["hits"] is not None and len(last["hits"]) < sure_hits:
-        sys.exit(f"bench self-check failed: {len(last['hits'])} hits < {sure_hits} planted pairs")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.emulate_world and run_head["hits"] is not None:
+        n_real = int(np.count_nonzero(run_head["hits"]["doc"] != pm.PM_DOC_COUNT))
+        if n_real < sure_hits:
+            log(f"bench self-check failed: {n_real} hits < {sure_hits} planted pairs")
+            ok = False
+    if rank == 0 and not ok:
+        log("bench self-check failed: scan modes disagree or planted hits are missing")
+    if rank == 0 and args.dump_hits and run_head["hits"] is not None:
+        # slots are numbered rank-major; name every record by its batch (position in the shape list)
+        # and re-order, so that runs with different shardings can be compared record by record
+        pos_of_slot = np.zeros(len(shapes), dtype=np.uint32)
+        for r in range(nparts):
+            for i, pos in enumerate(parts[r]):
+                pos_of_slot[bases[r] + i] = pos
+        h = run_head["hits"].copy()
+        h["slot"] = pos_of_slot[h["slot"]]
+        np.save(args.dump_hits, pm.sort_hits(np.ascontiguousarray(h)))
+    # every rank learns the verdict and leaves together (no rank waits in a barrier for one that exited)
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if ok and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,
                                            args.cpu_target_s, args.cpu_sample_gb, log)
-        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
+    if ok and rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

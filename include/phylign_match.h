@@ -143,6 +143,13 @@ int  pm_index_from_names(const char* names, size_t len, uint32_t n_docs, uint32_
 int  pm_index_drop_matrix(pm_index_t* idx);
 /* sets bit (rows[i], docs[i]) for i<n: planted hits for parity runs */
 int  pm_index_plant(pm_index_t* idx, const uint64_t* rows, const uint32_t* docs, size_t n);
+/* Measurement / test aid: synthetic "related batch" content.  Makes this index the HOME
+ * batch of queries q_first, q_first + q_step, ...: about half of its 32-document clusters
+ * match each of those queries at a k-mer fraction between 0.6 and 1.0 (k_plant_cluster),
+ * the shape real phylogenetic batches have for reads of their own species. */
+int  pm_index_plant_cluster(pm_index_t* idx, pm_queries_t* q, uint32_t q_first, uint32_t q_step, uint64_t seed);
+/* copies n rows starting at row0 (row_bytes each, file layout) back to the host (checks) */
+int  pm_index_read_rows(const pm_index_t* idx, uint64_t row0, uint64_t n, void* out);
 /* Measurement aid, not part of the matching path: times a pure random-row
  * gather over this index with k_scan's access pattern (n_groups row-cooperating
  * lane groups x lookups_per_group rows each, no counting); *ms = hipEvent time,

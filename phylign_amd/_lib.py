@@ -66,6 +66,8 @@ SYMBOLS = [
     ("pm_index_from_names", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("pm_index_drop_matrix", C.c_int, [_P]),
     ("pm_index_plant", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("pm_index_plant_cluster", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64]),
+    ("pm_index_read_rows", C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     ("pm_index_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("pm_index_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
     ("pm_index_device", C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -208,6 +210,15 @@ class Index:
         docs = np.ascontiguousarray(docs, dtype=np.uint32)
         assert rows.size == docs.size
         _chk(load().pm_index_plant(self._h, rows.ctypes.data, docs.ctypes.data, rows.size))
+
+    def plant_cluster(self, queries, q_first, q_step, seed=97):
+        """makes this index the home batch of queries q_first, q_first + q_step, ... (see the header)"""
+        _chk(load().pm_index_plant_cluster(self._h, queries._h, q_first, q_step, seed))
+
+    def read_rows(self, row0, n):
+        out = np.zeros((n, self.info.row_bytes), dtype=np.uint8)
+        _chk(load().pm_index_read_rows(self._h, row0, n, out.ctypes.data))
+        return out
 
     def probe_gather(self, n_groups, lookups_per_group):
         """(ms, algorithmic bytes) of a pure random-row gather with k_scan's access pattern"""

@@ -66,6 +66,7 @@ struct Ctx {
     std::vector<HitBuf> free_hits;
     unsigned long long* d_fetch = nullptr;
     pm_hit_t* h_stage = nullptr; uint64_t h_stage_cap = 0;   // pinned staging of raw records
+    uint64_t hit_hint = 0;                    // most records one search produced so far: sizes the next hit buffer
 };
 static Ctx g_ctx;
 // HIP's current device is a per-thread setting that starts at 0: every entry point
@@ -131,6 +132,8 @@ struct pm_queries {
     uint64_t epoch = 0;
 };
 
+static int upload_queries(pm_queries* q);
+static int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out);
 static const int kPlaneClass[4] = {7, 10, 16, 24};
 // pm_set_option("threshold_bound"): product default on; off reproduces the fetch-everything scan
 static uint32_t g_threshold_bound = 1;
@@ -627,6 +630,39 @@ extern "C" int pm_index_plant(pm_index_t* ix, const uint64_t* rows, const uint32
     if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
     hipFree(dr); if (dd) hipFree(dd);
     if (e != hipSuccess) return fail(PM_EHIP, "plant: %s", hipGetErrorString(e));
+    return PM_OK;
+}
+
+// Synthetic "related batch" content (measurement / test aid, see k_plant_cluster): makes this
+// index the HOME batch of queries q_first, q_first + q_step, ...: about half of its 32-document
+// clusters match each of those queries at a fraction between 0.6 and 1.0.
+extern "C" int pm_index_plant_cluster(pm_index_t* ix, pm_queries_t* q, uint32_t q_first, uint32_t q_step, uint64_t seed) {
+    NEED_DEV();
+    if (!ix || !q || !ix->d_matrix || q_step == 0) return fail(PM_EINVAL, "bad argument (planting works on classic indexes)");
+    if (ix->info.term_size != q->k) return fail(PM_EINVAL, "term_size mismatch");
+    const size_t nq = q->headers.size();
+    if (q_first >= nq) return PM_OK;
+    { int urc = upload_queries(q); if (urc) return urc; }
+    uint64_t* d_h = nullptr;
+    q->epoch++;
+    { int rc = ensure_hashes(q, (int)ix->info.canonicalize, ix->info.num_hashes, &d_h); if (rc) return rc; }
+    const uint32_t n_sel = (uint32_t)((nq - q_first + q_step - 1) / q_step);
+    uint32_t max_terms = 0;
+    for (size_t i = q_first; i < nq; i += q_step) max_terms = std::max(max_terms, q->n_terms[i]);
+    HIPCHK(launch_plant_cluster(ix->d_matrix, ix->info.stride, ix->info.signature_size, ix->info.n_docs, d_h, q->d_qd,
+                                ix->info.num_hashes, q_first, q_step, n_sel, max_terms, seed, g_ctx.stream));
+    HIPCHK(hipStreamSynchronize(g_ctx.stream));
+    return PM_OK;
+}
+
+// Copies rows [row0, row0 + n) (row_bytes each, file layout) back to the host: lets a test
+// rebuild the .cobs_classic file of a synthetic / planted index for the oracle.
+extern "C" int pm_index_read_rows(const pm_index_t* ix, uint64_t row0, uint64_t n, void* out) {
+    NEED_DEV();
+    if (!ix || !ix->d_matrix || !out || row0 + n > ix->info.signature_size) return fail(PM_EINVAL, "bad argument");
+    if (n == 0) return PM_OK;
+    HIPCHK(hipMemcpy2D(out, ix->info.row_bytes, ix->d_matrix + row0 * ix->info.stride, ix->info.stride,
+                       ix->info.row_bytes, n, hipMemcpyDeviceToHost));
     return PM_OK;
 }
 
@@ -1171,6 +1207,7 @@ extern "C" int pm_result_wait(pm_result_t* r) {
         const unsigned long long cnt = r->ws->h_cnt[0], runs = r->ws->h_cnt[1];
         if (cnt <= r->cap) {
             r->n_records = cnt; r->n_runs = runs;
+            if (cnt > g_ctx.hit_hint) g_ctx.hit_hint = cnt;
             break;
         }
         // hit buffer too small: grow to the exact count and run the job again
@@ -1215,7 +1252,8 @@ extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_
     pm_result* r = new pm_result();
     r->idx.assign(idx, idx + n_idx);
     r->q = q; r->threshold = threshold; r->nb_best = nb_best_hits; r->slot_base = slot_base;
-    const uint64_t want_cap = std::max<uint64_t>(1u << 20, (uint64_t)q->headers.size() * 16);
+    const uint64_t want_cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, (uint64_t)q->headers.size() * 16),
+                                                 g_ctx.hit_hint + g_ctx.hit_hint / 4);
     int rc = enqueue_search(r, want_cap);
     if (rc) {
         // whatever was queued before the failure must not outlive its buffers

@@ -67,6 +67,10 @@ hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t
                         uint64_t seed, uint32_t batch, hipStream_t st);
 hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
                                uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st);
+hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, uint32_t n_docs,
+                                const uint64_t* hashes, const QDesc* qd, uint32_t nh,
+                                uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms,
+                                uint64_t seed, hipStream_t st);
 hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
                         uint64_t n, hipStream_t st);
 

@@ -716,6 +716,64 @@ hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t 
     return hipGetLastError();
 }
 
+// Clustered true positives for the "phylogenetically related batch" workload: for every
+// selected query (its HOME batch is this index) the documents are taken in clusters of 32
+// (one dword of the row); cluster c gets a match fraction phi(query, c) from
+// {none x8, 0.60, 0.70, 0.75, 0.85, 0.93, 0.97, 1.0, 1.0} (half of the clusters unrelated) and
+// every k-mer row of the query gets, in that dword, an OR-mask of independent bits of density phi.
+// So many documents end up near the 0.7 threshold, above and below it.  One thread per
+// (selected query, k-mer, dword).  Set-up only, never timed.
+__global__ __launch_bounds__(256) void k_plant_cluster(
+    uint8_t* matrix, uint64_t stride, uint64_t S, uint64_t bm, uint32_t n_docs,
+    const uint64_t* __restrict__ hashes, const QDesc* __restrict__ qd, uint32_t nh,
+    uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms, uint64_t seed)
+{
+    const uint32_t n_dw = (n_docs + 31u) >> 5;
+    const uint64_t total = (uint64_t)n_sel * max_terms * n_dw;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t dw = (uint32_t)(i % n_dw);
+        const uint64_t r1 = i / n_dw;
+        const uint32_t t = (uint32_t)(r1 % max_terms);
+        const uint32_t qi = q_first + (uint32_t)(r1 / max_terms) * q_step;
+        const QDesc d = qd[qi];
+        if (t >= d.n_terms) continue;
+        const uint64_t kc = splitmix64(seed ^ ((uint64_t)qi * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)dw << 40));
+        const uint32_t sel = (uint32_t)(kc & 15u);
+        if (sel < 8u) continue;                                    // unrelated cluster
+        const uint32_t lut[8] = {154u, 179u, 192u, 218u, 238u, 248u, 256u, 256u};   // phi * 256
+        const uint32_t cut = lut[sel - 8u];
+        uint32_t m = 0;
+        uint64_t x = splitmix64(kc + 0x51ED270B1ULL * (t + 1u));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            x = splitmix64(x + (uint64_t)w);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) m |= (((uint32_t)(x >> (8 * b)) & 255u) < cut ? 1u : 0u) << (8 * w + b);
+        }
+        const uint32_t first = dw * 32u;
+        if (first + 32u > n_docs) m &= (1u << (n_docs - first)) - 1u;
+        if (m == 0u) continue;
+        for (uint32_t j = 0; j < nh; ++j) {
+            const uint64_t h = hashes[((uint64_t)d.pad_blk + (t >> 3)) * nh * 8 + (uint64_t)j * 8 + (t & 7u)];
+            uint32_t* w = reinterpret_cast<uint32_t*>(matrix + mod_sig(h, S, bm) * stride + (uint64_t)dw * 4);
+            atomicOr(w, m);
+        }
+    }
+}
+hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, uint32_t n_docs,
+                                const uint64_t* hashes, const QDesc* qd, uint32_t nh,
+                                uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms,
+                                uint64_t seed, hipStream_t st) {
+    const uint64_t total = (uint64_t)n_sel * max_terms * ((n_docs + 31u) >> 5);
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL(k_plant_cluster, dim3((uint32_t)blocks), dim3(256), 0, st, matrix, stride, S, barrett_m(S),
+                       n_docs, hashes, qd, nh, q_first, q_step, n_sel, max_terms, seed);
+    return hipGetLastError();
+}
+
 __global__ void k_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -1,0 +1,224 @@
+"""Round-2 device paths on the GPU, against the oracle: hit lists written as ordered
+runs by the scan kernel (a7 on the device), searches in flight (pm_search_async), the
+clustered "home batch" content, the gathered-bytes counter, GPU binding of worker threads."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import build_case, doc_names, rand_seq
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _names(ix):
+    return [ix.doc_name(d) for d in range(ix.info.n_docs)]
+
+
+def _file_of(oracle, ix):
+    """the .cobs_classic bytes of an index that lives in HBM (synthetic / planted content)"""
+    info = ix.info
+    rows = ix.read_rows(0, info.signature_size)
+    return oracle.make_index(info.term_size, info.canonicalize, info.signature_size, info.num_hashes, _names(ix), rows)
+
+
+@pytest.mark.parametrize("n_docs,S,qlen", [(664, 6000, 150), (4000, 2500, 150), (100, 3000, 150), (13, 2000, 400),
+                                            (1300, 1500, 1500), (9001, 700, 150)])
+@pytest.mark.parametrize("layout", [1, 2])
+def test_clustered_home_batch_text_bit_exact(pm, oracle, n_docs, S, qlen, layout):
+    """long hit lists with many distinct scores and ties: the runs the kernel writes are cobs' lines"""
+    rng = np.random.default_rng(n_docs + qlen)
+    nq = 24
+    queries = [(f"c{i} x", rand_seq(rng, qlen)) for i in range(nq)]
+    fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
+    q = pm.Queries(fasta)
+    ix = pm.Index.synth(3, n_docs, S, seed=661, layout=layout)
+    ix.plant_cluster(q, 0, 2, seed=97)                      # every second query is at home here
+    index = _file_of(oracle, ix)
+    for thr in (0.7, 0.5, 0.0):
+        exp = oracle.query_file(index, fasta, thr)
+        for bound in (1, 0):
+            pm.set_option("threshold_bound", bound)
+            assert pm.query_text(ix, fasta, thr) == exp, (thr, bound)
+        pm.set_option("threshold_bound", 1)
+    exp = oracle.query_file(index, fasta, 0.7).decode()
+    assert exp.count("\n") > nq + nq // 2 * min(n_docs, 32) // 2
+    from phylign_amd import postprocess as P
+    for n in (1, 3, 100):
+        assert pm.query_text(ix, fasta, 0.7, nb_best_hits=n).decode() == P.filter_text(exp, n)
+
+
+def test_device_records_are_ordered_runs(pm, oracle):
+    """raw records in HBM: one run per (query, slot) = count record + hits in cobs line order"""
+    rng = np.random.default_rng(77)
+    n_docs, S = 664, 5000
+    queries = [(f"r{i}", rand_seq(rng, 150)) for i in range(40)]
+    plant = [(qi, (qi * 7 + 3 * j) % n_docs, fr) for qi in range(0, 40, 2)
+             for j, fr in enumerate((1.0, 0.9, 0.9, 0.8, 0.8, 0.8, 0.75, 0.7, 0.7, 0.6))]
+    index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant)
+    ix = pm.Index.load_mem(index)
+    q = pm.Queries(fasta)
+    import torch
+    for n in (0, 3):
+        res = pm.search([ix, ix], q, 0.7, slot_base=5, nb_best_hits=n)
+        st = res.stats
+        assert st.n_records == st.n_hits + st.n_runs and st.n_runs >= 2 * 20
+        buf = torch.zeros((st.n_records, 4), dtype=torch.int32, device="cuda")
+        res.copy_hits_device(buf.data_ptr(), st.n_records)
+        raw = buf.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+        heads = np.flatnonzero(raw["doc"] == pm.PM_DOC_COUNT)
+        assert heads[0] == 0 and len(heads) == st.n_runs
+        ends = list(heads[1:]) + [len(raw)]
+        seen = set()
+        for b, e in zip(heads, ends):
+            run = raw[b + 1:e]
+            assert len(run) and (run["query"] == raw[b]["query"]).all() and (run["slot"] == raw[b]["slot"]).all()
+            key = list(zip(-run["score"].astype(np.int64), run["doc"]))
+            assert key == sorted(key)
+            assert raw[b]["score"] >= len(run) and (n or raw[b]["score"] == len(run))
+            seen.add((int(raw[b]["slot"]), int(raw[b]["query"])))
+        assert len(seen) == st.n_runs                       # one run per (slot, query)
+        host = res.hits()
+        assert pm.format_hits(ix, q, host, slot=6, nb_best_hits=n if n else -1) == \
+            pm.format_hits(ix, q, raw, slot=6, nb_best_hits=n if n else -1)   # raw runs format the same
+        assert np.array_equal(pm.sort_hits(host.copy()), host)
+
+
+def test_searches_in_flight_give_the_same_records(pm, oracle):
+    rng = np.random.default_rng(78)
+    queries = [(f"a{i}", rand_seq(rng, 150)) for i in range(64)]
+    cases = [build_case(oracle, rng, d, s, queries, plant=[(i, (i * 5) % d, 0.8) for i in range(0, 64, 3)])
+             for d, s in ((300, 4000), (4000, 1500))]
+    ixs = [pm.Index.load_mem(c[0]) for c in cases]
+    q = pm.Queries(cases[0][1])
+    want = [pm.search([ixs[0]], q, 0.7).hits(), pm.search(ixs, q, 0.7, slot_base=2).hits(),
+            pm.search([ixs[1]], q, 0.3, nb_best_hits=2).hits()]
+    inflight = [pm.search_async([ixs[0]], q, 0.7), pm.search_async(ixs, q, 0.7, slot_base=2),
+                pm.search_async([ixs[1]], q, 0.3, nb_best_hits=2), pm.search_async([ixs[0]], q, 0.7)]
+    got = [r.hits() for r in reversed(inflight)][::-1]      # collected out of order
+    for g, w in zip(got, want + [want[0]]):
+        assert np.array_equal(g, w)
+    r = pm.search_async(ixs, q, 0.7)
+    r.free()                                                # freeing an unfinished search is safe
+    assert np.array_equal(pm.search([ixs[0]], q, 0.7).hits(), want[0])
+
+
+@pytest.mark.parametrize("thr", [0.7, 0.0])
+def test_gathered_bytes_counter(pm, oracle, thr):
+    rng = np.random.default_rng(79)
+    q = pm.Queries("".join(f">g{i}\n{rand_seq(rng, 150)}\n" for i in range(300)).encode())
+    ixs = [pm.Index.synth(b, d, s, seed=661) for b, (d, s) in enumerate(((664, 30000), (4000, 9000), (100, 20000), (9001, 2000)))]
+    pm.set_option("count_fetched", 1)
+    try:
+        out = {}
+        for bound in (0, 1):
+            pm.set_option("threshold_bound", bound)
+            res = pm.search(ixs, q, thr)
+            st = res.stats
+            out[bound] = (res.hits(), st.fetched_bytes, st.algorithmic_bytes,
+                          [(L["fetched_bytes"], L["algorithmic_bytes"]) for L in res.launches()])
+        assert np.array_equal(out[0][0], out[1][0])
+        assert out[0][1] == out[0][2] == 300 * 120 * (83 + 500 + 13 + 1126)      # fetch-all gathers every row byte
+        assert all(f == a for f, a in out[0][3])
+        if thr > 0:
+            assert 0.2 * out[1][2] < out[1][1] < 0.8 * out[1][2]                  # the bound skips dead lines
+        else:
+            assert out[1][1] == out[1][2]                                          # threshold 0: nothing is ever out
+    finally:
+        pm.set_option("count_fetched", 0)
+        pm.set_option("threshold_bound", 1)
+    res = pm.search(ixs, q, thr)
+    assert res.stats.fetched_bytes == 0
+
+
+def test_worker_threads_use_the_bound_gpu(pm, oracle):
+    """HIP's current device is per thread: loads from a thread pool must land on pm_init()'s GPU"""
+    rng = np.random.default_rng(80)
+    index, fasta, _ = build_case(oracle, rng, 300, 3000, [("w0", rand_seq(rng, 150))], plant=[(0, 7, 1.0)])
+    out = []
+
+    def work():
+        ix = pm.Index.load_mem(index)
+        out.append((ix.device, pm.query_text(ix, fasta, 0.7)))
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(out) == 4
+    for devno, text in out:
+        assert devno == pm.bound_device() == 0 and text == oracle.query_file(index, fasta, 0.7)
+    assert pm.Index.load_header_mem(index).device == -1
+
+
+def test_second_gpu_binding_when_present(pm, oracle):
+    """on a multi-GPU node: a process bound to GPU 1 keeps its matrices there, also from threads"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    code = (
+        "import sys, threading; sys.path.insert(0, %r)\n"
+        "from phylign_amd import _lib as pm\n"
+        "pm.init(1)\n"
+        "out = []\n"
+        "def work():\n"
+        "    out.append(pm.Index.synth(0, 300, 5000).device)\n"
+        "ts = [threading.Thread(target=work) for _ in range(3)]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n"
+        "assert out == [1, 1, 1], out\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+
+
+def test_names_without_separator_are_cut_on_the_host(pm, oracle):
+    """scripts/postprocess_cobs.py:10-18 raises on a line without '_' once its rank reaches n; an
+    index with such a name is therefore never cut on the GPU, so the host rule sees every line"""
+    rng = np.random.default_rng(81)
+    n_docs, S = 200, 4000
+    queries = [(f"n{i}", rand_seq(rng, 150)) for i in range(8)]
+    plant = [(qi, d, fr) for qi in range(8) for d, fr in ((5, 1.0), (9, 0.9), (11, 0.8), (20, 0.75), (21, 0.72))]
+    rb = (n_docs + 7) // 8
+    bits = rng.random((S, rb * 8)) < 0.05
+    bits[:, n_docs:] = False
+    matrix = np.packbits(bits, axis=1, bitorder="little")
+    for qi, doc, frac in plant:
+        hs = oracle.create_hashes(queries[qi][1].encode(), 31, 1, 1)
+        for t in range(int(np.ceil(frac * len(hs)))):
+            matrix[int(hs[t]) % S, doc >> 3] |= np.uint8(1 << (doc & 7))
+    names = doc_names(rng, n_docs)
+    names[21] = "nounderscore"                                  # the worst hit of every query
+    index = oracle.make_index(31, 1, S, 1, names, matrix)
+    fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
+    ix = pm.Index.load_mem(index)
+    q = pm.Queries(fasta)
+    got = pm.search([ix], q, 0.7, nb_best_hits=2).hits()
+    assert not (got["doc"] == pm.PM_DOC_COUNT).any() and len(got) == 8 * 5     # nothing was cut on the GPU
+    with pytest.raises(pm.PMError):                                           # the reference raises as well (rank 5 >= n)
+        pm.format_hits(ix, q, got, nb_best_hits=2)
+    assert pm.format_hits(ix, q, got, nb_best_hits=-1) == oracle.query_file(index, fasta, 0.7)
+
+
+def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
+    """the N>1 bench path (static sharding + packed gather, two ranks sharing the GPU over gloo)
+    returns exactly the records of the single-rank run"""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    common = ["--steps", "2", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline"]
+    one = tmp_path / "one.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(one)],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    import json
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["threshold_bound"]["hits_identical_to_headline"] and line["clustered"]["hits_identical"]
+    assert line["roofline"]["frac"] < 1.0 and line["threshold_bound"]["roofline"]["frac"] < 1.0
+    assert line["clustered"]["fetch_all_rows"]["hits"] > 20 * line["hits"]
+    two = tmp_path / "two.npy"
+    env2 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2"] + common + ["--dump-hits", str(two)], capture_output=True, env=env2)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    a, b = np.load(one), np.load(two)
+    assert len(a) > 50 and np.array_equal(a, b)

@@ -204,6 +204,7 @@ def main():
     pg_dev = "cuda" if backend == "nccl" else "cpu"
     packed = PackedGather(1 << 16, pg_dev)          # 64 Ki records (1 MiB) per rank in one collective
     last = {}
+    kept = []        # results whose pinned records are still referenced (freed at the end)
     phase = {"queue": 0.0, "wait": 0.0, "host": 0.0, "gather": 0.0}
 
     def queue_step():
@@ -212,49 +213,71 @@ def main():
         phase["queue"] += time.perf_counter() - t_a
         return res
 
-    def finish_step(res, groups=None):
+    def finish_step(res, groups=None, keep=False):
         t_a = time.perf_counter()
         res.wait()
         st = res.stats
         t_b = time.perf_counter()
-        # every rank brings its own records to its host in cobs order (the kernel wrote each hit list
-        # as an ordered run; the host only orders the runs); ranks own disjoint, increasing slot
+        # a7 ordering happens on the device (the kernel wrote each hit list as an ordered run, the host
+        # orders the run directory, k_permute_runs moves the runs); ranks own disjoint, increasing slot
         # ranges, so the rank-order concatenation that the gather produces on rank 0 is globally ordered
-        mine_sorted = res.hits()
-        n_local = len(mine_sorted)
-        t_c = time.perf_counter()
+        host = None
         if world == 1:
-            host = mine_sorted
-        else:
-            t = torch.from_numpy(mine_sorted.view(np.int32).reshape(-1, 4))
+            host = res.hits(copy=False)                    # view of the library's pinned buffer (lives as long as `res`)
+            t_c = time.perf_counter()
+        elif pg_dev == "cuda":
+            _, n_local = res.ordered_device()
+            t_c = time.perf_counter()
+            if n_local <= packed.cap:
+                res.copy_hits_device(packed.records_view().data_ptr(), packed.cap, ordered=True)
+                g = packed.gather(n_local)
+            else:
+                big = torch.empty((n_local, 4), dtype=torch.int32, device="cuda")
+                res.copy_hits_device(big.data_ptr(), n_local, ordered=True)
+                g = packed.gather(n_local, overflow=big)
+            if rank == 0:
+                host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+        else:                                              # gloo: functional check of the same sequence
+            mine_sorted = res.hits(copy=False)
+            n_local = len(mine_sorted)
+            t_c = time.perf_counter()
+            t = torch.from_numpy(mine_sorted.view(np.int32).reshape(-1, 4).copy())
             if n_local <= packed.cap:
                 packed.records_view()[:n_local].copy_(t)
                 g = packed.gather(n_local)
             else:
-                g = packed.gather(n_local, overflow=t.cuda() if pg_dev == "cuda" else t)
-            host = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1) if rank == 0 else None
+                g = packed.gather(n_local, overflow=t)
+            if rank == 0:
+                host = g.numpy().view(pm.HIT_DTYPE).reshape(-1).copy()
         t_d = time.perf_counter()
         phase["wait"] += t_b - t_a; phase["host"] += t_c - t_b; phase["gather"] += t_d - t_c
-        last["stats"], last["hits"] = st, host
+        last["stats"] = st
+        last["n_hits"] = len(host) if host is not None else None
         if groups is not None:
             for L in res.launches():
                 g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])   # [algorithmic bytes, ms, launches, batches]
                 g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
-        res.free()
+        if keep:
+            # the records of the last step stay for the cross-mode comparison: keep the result alive
+            # instead of copying hundreds of MB inside the timed region
+            last["hits"] = host
+            kept.append(res)
+        else:
+            res.free()
 
-    def run_steps(n, groups=None):
+    def run_steps(n, groups=None, keep_last=False):
         """n steps; unless --no-pipeline the kernels of step i+1 are queued before step i is finished"""
         prev = None
-        for _ in range(n):
+        for i in range(n):
             cur = queue_step()
             if args.no_pipeline:
-                finish_step(cur, groups)
+                finish_step(cur, groups, keep_last and i == n - 1)
                 continue
             if prev is not None:
                 finish_step(prev, groups)
             prev = cur
         if prev is not None:
-            finish_step(prev, groups)
+            finish_step(prev, groups, keep_last)
 
     def timed_run(bound, warmup, steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks"""
@@ -265,14 +288,15 @@ def main():
             phase[k] = 0.0
         groups = {}      # kernel instantiation -> [algorithmic bytes, ms, launches, batches] over the timed steps
         t_start = time.perf_counter()
-        run_steps(steps, groups)
+        run_steps(steps, groups, keep_last=True)
         sync()
         elapsed = time.perf_counter() - t_start
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return {"elapsed": elapsed, "groups": groups, "phase": dict(phase), "hits": last["hits"], "stats": last["stats"]}
+        return {"elapsed": elapsed, "groups": groups, "phase": dict(phase), "hits": last.get("hits"),
+                "n_hits": last.get("n_hits"), "stats": last["stats"]}
 
     def fetched_pass(bound):
         """one untimed search with the in-kernel counter on: algorithmic bytes really gathered, per kernel"""
@@ -330,7 +354,11 @@ def main():
         out = {"value": n_terms / el, "unit": "k-mers/s", "ms_per_step": el * 1e3,
                "hbm_fraction_whole_step_algorithmic": alg_total / el / (HBM_PEAK_GBPS * 1e9 * world),
                "roofline": roofline_of(run, steps, mode, fetched),
-               "hits": int(len(run["hits"])) if run["hits"] is not None else None}
+               "hits": run["n_hits"],
+               "rank0_ms": {"kernels_total": run["stats"].ms_total,
+                            "host_wait_for_gpu": run["phase"]["wait"] / steps * 1e3,
+                            "run_order_on_device_and_d2h": run["phase"]["host"] / steps * 1e3,
+                            "hit_gather": run["phase"]["gather"] / steps * 1e3}}
         if fetched:
             tot_f = sum(v[0] for v in fetched.values()); tot_a = sum(v[1] for v in fetched.values())
             out["fraction_of_row_bytes_gathered_rank0"] = tot_f / tot_a if tot_a else None
@@ -352,7 +380,7 @@ def main():
     sum_other = None
     ok = True
     if full:
-        run_other = timed_run(other == "threshold_bound", 1, args.steps)
+        run_other = timed_run(other == "threshold_bound", 1, args.steps)      # pools are warm: same record volume
         fetched_other = fetched_pass(other == "threshold_bound")
         sum_other = summary(run_other, args.steps, other, fetched_other)
         same = bool(rank != 0 or np.array_equal(run_head["hits"], run_other["hits"]))
@@ -369,7 +397,9 @@ def main():
         log(f"[bench] clustered planting {time.time() - t0:.1f}s")
         c_runs = {}
         for m in modes:
-            r = timed_run(m == "threshold_bound", 1, args.steps)
+            # 3 warm-up steps: the hit lists are ~700x longer here, and the pooled device / pinned
+            # buffers of two searches in flight are (re)allocated once, outside the timed steps
+            r = timed_run(m == "threshold_bound", 3, args.steps)
             c_runs[m] = (r, fetched_pass(m == "threshold_bound"))
         same = bool(rank != 0 or np.array_equal(c_runs[modes[0]][0]["hits"], c_runs[modes[1]][0]["hits"]))
         ok = ok and same
@@ -411,8 +441,8 @@ def main():
         "rank0_ms": {"kernels_total": st_head.ms_total, "hash": st_head.ms_hash, "scan": st_head.ms_scan,
                      "host_queue_launches": ph["queue"] / args.steps * 1e3,
                      "host_wait_for_gpu": ph["wait"] / args.steps * 1e3,
-                     "host_d2h_and_run_order": ph["host"] / args.steps * 1e3,
-                     "host_hit_gather": ph["gather"] / args.steps * 1e3},
+                     "run_order_on_device_and_d2h": ph["host"] / args.steps * 1e3,
+                     "hit_gather": ph["gather"] / args.steps * 1e3},
         "scan_launches": {k: {"launches_per_step": v[2] / args.steps, "batches": v[3], "avg_ms": v[1] / v[2],
                               "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in run_head["groups"].items()},
         "roofline": sum_head["roofline"],

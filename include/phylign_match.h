@@ -207,13 +207,18 @@ int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
 int  pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size_t* n);
 /* raw (unordered) records in HBM, e.g. as the send buffer of the RCCL gather */
 int  pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n);
-/* D2D copy of the records into caller-owned device memory (a torch tensor) */
-int  pm_result_copy_hits_device(const pm_result_t* r, void* dst_dptr, uint64_t capacity);
-/* D2H copy into caller-owned host memory (capacity in records, >= pm_stats_t.n_records),
- * ordered there by (slot, query, score desc, doc asc); *n_out = records written */
+/* the records in HBM after the device-side ordering (runs moved into (slot, query) order
+ * by k_permute_runs, count records kept only where a list was cut): the send buffer of
+ * the RCCL gather.  Valid until pm_result_free. */
+int  pm_result_ordered_device(pm_result_t* r, const void** dptr, uint64_t* n);
+/* D2D copy of the records (ordered != 0: after the device-side ordering, else raw runs)
+ * into caller-owned device memory, e.g. a torch tensor that RCCL sends */
+int  pm_result_copy_hits_device(pm_result_t* r, void* dst_dptr, uint64_t capacity, int ordered);
+/* D2H copy of the ordered records into caller-owned host memory (capacity in records;
+ * pm_stats_t.n_records always suffices): (slot, query, score desc, doc asc); *n_out = records written */
 int  pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity, uint64_t* n_out);
 /* records on the host ordered by (slot, query, score desc, doc asc);
- * library-owned, valid until pm_result_free */
+ * library-owned pinned memory, valid until pm_result_free */
 int  pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n);
 void pm_result_free(pm_result_t* r);
 /* orders records in place by (slot, query, score desc, doc asc): the order of

@@ -86,7 +86,8 @@ SYMBOLS = [
     ("pm_result_launches", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pm_hits_sort", None, [_P, C.c_uint64]),
     ("pm_result_hits_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
-    ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64]),
+    ("pm_result_ordered_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("pm_result_copy_hits_device", C.c_int, [_P, _P, C.c_uint64, C.c_int]),
     ("pm_result_hits_into", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_free", None, [_P]),
@@ -326,23 +327,32 @@ class Result:
         _chk(load().pm_result_hits_device(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def copy_hits_device(self, dst_ptr, capacity):
-        _chk(load().pm_result_copy_hits_device(self._h, dst_ptr, capacity))
+    def copy_hits_device(self, dst_ptr, capacity, ordered=False):
+        _chk(load().pm_result_copy_hits_device(self._h, dst_ptr, capacity, int(ordered)))
 
     def wait(self):
         """blocks until the GPU has finished this search (results of search_async)"""
         _chk(load().pm_result_wait(self._h))
         return self
 
-    def hits(self):
+    def ordered_device(self):
+        """(device pointer, n) of the records after the device-side ordering (RCCL send buffer)"""
+        p, n = _P(), C.c_uint64()
+        _chk(load().pm_result_ordered_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def hits(self, copy=True):
         """numpy structured array (HIT_DTYPE) ordered (slot, query, score desc, doc asc);
         a count record (doc == PM_DOC_COUNT) leads the hits of a (query, slot) whose list
-        was cut to the n best on the GPU."""
-        cap = int(self.stats.n_records)
-        out = np.empty(cap, dtype=HIT_DTYPE)
-        n = C.c_uint64()
-        _chk(load().pm_result_hits_into(self._h, out.ctypes.data, cap, C.byref(n)))
-        return out[: n.value]
+        was cut to the n best on the GPU.  copy=False returns a view of the library's pinned
+        buffer: valid only until this Result is freed."""
+        p, n = _P(), C.c_uint64()
+        _chk(load().pm_result_hits_host(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.empty(0, dtype=HIT_DTYPE)
+        buf = (C.c_char * (n.value * HIT_DTYPE.itemsize)).from_address(p.value)
+        view = np.frombuffer(buf, dtype=HIT_DTYPE)
+        return view.copy() if copy else view
 
     def free(self):
         if self._h:

@@ -44,13 +44,19 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 struct HitBuf { uint4* p; uint64_t cap; };
+struct PinBuf { void* p; size_t bytes; };
 // Per-search scratch that must stay untouched while the search is in flight (several
 // searches may be queued back to back: pm_search_async): record counters with their pinned
 // mirror, batch descriptors, timing events.  Pooled in the context, grow-only.
 struct Workspace {
     unsigned long long* d_cnt = nullptr;      // [0] records written, [1] runs
-    unsigned long long* h_cnt = nullptr;      // pinned mirror, filled by an async copy behind the kernels
+    unsigned long long* h_cnt = nullptr;      // pinned, device-mapped mirror: written by k_publish behind the scans
+    unsigned long long* h_cnt_dev = nullptr;  // its device address
+    // batch descriptors: 5 slices of desc_cap entries (base + one per query counter-width class, which
+    // carries the block ranges of a mixed-width launch); `uploaded` is what the device copy holds, so
+    // a step loop over the same indexes uploads nothing (and puts no DMA on the compute stream)
     BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr; size_t desc_cap = 0;
+    std::vector<BatchDesc> uploaded;
     std::vector<hipEvent_t> events;
     hipEvent_t done = nullptr;                // recorded behind the counter read-back
     bool busy = false;
@@ -64,8 +70,8 @@ struct Ctx {
     hipStream_t d2h_stream = nullptr;         // hit records to the host: never queues behind later kernels
     std::vector<Workspace*> ws;
     std::vector<HitBuf> free_hits;
+    std::vector<PinBuf> free_pinned;
     unsigned long long* d_fetch = nullptr;
-    pm_hit_t* h_stage = nullptr; uint64_t h_stage_cap = 0;   // pinned staging of raw records
     uint64_t hit_hint = 0;                    // most records one search produced so far: sizes the next hit buffer
 };
 static Ctx g_ctx;
@@ -183,7 +189,7 @@ extern "C" void pm_shutdown(void) {
     }
     for (auto& b : g_ctx.free_hits) hipFree(b.p);
     if (g_ctx.d_fetch) hipFree(g_ctx.d_fetch);
-    if (g_ctx.h_stage) hipHostFree(g_ctx.h_stage);
+    for (auto& b : g_ctx.free_pinned) hipHostFree(b.p);
     g_ctx = Ctx();
 }
 
@@ -949,7 +955,9 @@ static int ws_event(Workspace* w, size_t i, hipEvent_t* ev) {
     *ev = w->events[i];
     return PM_OK;
 }
+static inline uint64_t run_cap_of(uint64_t cap) { return cap / 2 + 1; }
 static int take_hit_buffer(uint64_t cap, HitBuf* out) {
+    if (cap >= 0xFFFFFFF0ull) return fail(PM_ERANGE, "more than 2^32 hit records in one search: split the query set");
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         size_t best = g_ctx.free_hits.size();          // the largest pooled buffer that is big enough
@@ -963,16 +971,62 @@ static int take_hit_buffer(uint64_t cap, HitBuf* out) {
         }
     }
     out->cap = cap;
-    HIPCHK(hipMalloc((void**)&out->p, cap * sizeof(uint4)));
+    // `cap` records followed by the run directory (a run holds at least two records)
+    HIPCHK(hipMalloc((void**)&out->p, (cap + run_cap_of(cap)) * sizeof(uint4)));
     return PM_OK;
 }
 static void give_hit_buffer(HitBuf b) {
     if (!b.p) return;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_ctx.ready && g_ctx.free_hits.size() < 3) { g_ctx.free_hits.push_back(b); return; }
+        // raw + ordered buffers of two searches in flight must all come from the pool: hipFree
+        // waits for the device, i.e. for the kernels of the NEXT search, and would undo the overlap
+        if (g_ctx.ready) {
+            g_ctx.free_hits.push_back(b);
+            if (g_ctx.free_hits.size() <= 8) return;
+            size_t small = 0;                              // pool full: the smallest buffer goes
+            for (size_t i = 1; i < g_ctx.free_hits.size(); ++i) if (g_ctx.free_hits[i].cap < g_ctx.free_hits[small].cap) small = i;
+            b = g_ctx.free_hits[small];
+            g_ctx.free_hits.erase(g_ctx.free_hits.begin() + (long)small);
+        }
     }
     hipFree(b.p);
+}
+
+// pinned host buffers (results on the host, staging): pooled, since pinning memory is slow
+static int take_pinned(size_t bytes, PinBuf* out) {
+    bytes = std::max<size_t>(bytes, 1 << 16);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_ctx.free_pinned.size();          // the smallest pooled buffer that is big enough
+        for (size_t i = 0; i < g_ctx.free_pinned.size(); ++i)
+            if (g_ctx.free_pinned[i].bytes >= bytes && (best == g_ctx.free_pinned.size() || g_ctx.free_pinned[i].bytes < g_ctx.free_pinned[best].bytes))
+                best = i;
+        if (best != g_ctx.free_pinned.size()) {
+            *out = g_ctx.free_pinned[best];
+            g_ctx.free_pinned.erase(g_ctx.free_pinned.begin() + (long)best);
+            return PM_OK;
+        }
+    }
+    bytes += bytes / 4;
+    out->bytes = bytes;
+    HIPCHK(hipHostMalloc(&out->p, bytes, hipHostMallocDefault));
+    return PM_OK;
+}
+static void give_pinned(PinBuf b) {
+    if (!b.p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_ctx.ready) {
+            g_ctx.free_pinned.push_back(b);
+            if (g_ctx.free_pinned.size() <= 8) return;
+            size_t small = 0;                              // pool full: the smallest buffer goes
+            for (size_t i = 1; i < g_ctx.free_pinned.size(); ++i) if (g_ctx.free_pinned[i].bytes < g_ctx.free_pinned[small].bytes) small = i;
+            b = g_ctx.free_pinned[small];
+            g_ctx.free_pinned.erase(g_ctx.free_pinned.begin() + (long)small);
+        }
+    }
+    hipHostFree(b.p);
 }
 
 // One scan unit per classic index or per sub-index of a compact index.
@@ -999,14 +1053,21 @@ struct pm_result {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> lev;
     unsigned long long* h_fetch = nullptr;       // pinned [launch][kFetchShards] when "count_fetched" is on
-    // host copy
-    std::vector<pm_hit_t> host;
+    // ordered form (ensure_ordered): records permuted on the device into (slot, query) run order
+    bool ordered = false;
+    HitBuf d_ord{nullptr, 0};
+    uint64_t n_out = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> fixups;   // [begin, end) of (slot, query) groups merged from several runs
+    // host copy (pinned, pooled)
+    PinBuf host{nullptr, 0};
     bool host_ready = false;
 };
 
 static void result_release(pm_result* r) {
     give_hit_buffer(HitBuf{r->d_hits, r->cap});
     r->d_hits = nullptr; r->cap = 0;
+    give_hit_buffer(r->d_ord); r->d_ord = HitBuf{nullptr, 0};
+    give_pinned(r->host); r->host = PinBuf{nullptr, 0};
     give_workspace(r->ws); r->ws = nullptr;
     if (r->h_fetch) { hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
 }
@@ -1069,20 +1130,23 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     Workspace* ws = r->ws;
     if (!ws->d_cnt) {
         HIPCHK(hipMalloc((void**)&ws->d_cnt, 4 * sizeof(unsigned long long)));
-        HIPCHK(hipHostMalloc((void**)&ws->h_cnt, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&ws->h_cnt, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void**)&ws->h_cnt_dev, ws->h_cnt, 0));
         HIPCHK(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     }
     if (ws->desc_cap < n_units) {
         if (ws->d_desc) hipFree(ws->d_desc);
         if (ws->h_desc) hipHostFree(ws->h_desc);
         ws->d_desc = nullptr; ws->h_desc = nullptr; ws->desc_cap = 0;
+        ws->uploaded.clear();
         const size_t cap = std::max<size_t>(n_units, 64);
-        HIPCHK(hipMalloc((void**)&ws->d_desc, cap * sizeof(BatchDesc)));
-        // 1 + 4 slices: the base descriptors and one staging slice per query counter-width class
-        // (mixed-width launches patch block ranges per class; a slice is never rewritten within a search)
+        HIPCHK(hipMalloc((void**)&ws->d_desc, 5 * cap * sizeof(BatchDesc)));
         HIPCHK(hipHostMalloc((void**)&ws->h_desc, 5 * cap * sizeof(BatchDesc), hipHostMallocDefault));
         ws->desc_cap = cap;
     }
+    // host image of all five slices: base descriptors, then per query class the block ranges of mixed launches
+    const size_t dcap = ws->desc_cap;
+    memset(ws->h_desc, 0, 5 * dcap * sizeof(BatchDesc));
     {
         size_t o = 0;
         for (auto& g : groups)
@@ -1094,8 +1158,33 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
                 d.slot = units[u].slot; d.doc_base = units[u].doc_base; d.prune = units[u].prune ? 1u : 0u;
                 d.lanes = (uint32_t)ix->g; d.block_begin = 0; d.pad_ = 0;
             }
-        if (n_units)
-            HIPCHK(hipMemcpyAsync(ws->d_desc, ws->h_desc, n_units * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
+    }
+    std::vector<uint32_t> mixed_blocks(groups.size() * 4, 0u);
+    {
+        size_t desc_off = 0;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            Group& g = groups[gi];
+            if (g.g == 0)
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
+                    if (e == b) continue;
+                    uint64_t blk = 0;
+                    BatchDesc* stage = ws->h_desc + (size_t)(1 + c) * dcap + desc_off;
+                    for (size_t k = 0; k < g.members.size(); ++k) {
+                        stage[k] = ws->h_desc[desc_off + k];
+                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes);
+                        stage[k].block_begin = (uint32_t)blk;
+                        blk += (e - b + qpb - 1) / qpb;
+                    }
+                    if (blk > 0x7FFFFFFFull) return fail(PM_ERANGE, "launch grid too large");
+                    mixed_blocks[gi * 4 + (size_t)c] = (uint32_t)blk;
+                }
+            desc_off += g.members.size();
+        }
+    }
+    if (ws->uploaded.size() != 5 * dcap || memcmp(ws->uploaded.data(), ws->h_desc, 5 * dcap * sizeof(BatchDesc)) != 0) {
+        HIPCHK(hipMemcpyAsync(ws->d_desc, ws->h_desc, 5 * dcap * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
+        ws->uploaded.assign(ws->h_desc, ws->h_desc + 5 * dcap);
     }
     // per-query minimum score, cached on the query set per threshold value
     if (nq && (!q->d_thr || q->thr_for != r->threshold)) {
@@ -1145,25 +1234,16 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
                 const uint32_t qpb = scan_queries_per_block(g.g);
                 a.tiles = (e - b + qpb - 1) / qpb;
             } else {
-                // mixed widths: per-batch workgroup ranges for this query class go into the descriptors
-                uint64_t blk = 0;
-                BatchDesc* stage = ws->h_desc + (size_t)(1 + c) * ws->desc_cap + desc_off;
-                for (size_t k = 0; k < g.members.size(); ++k) {
-                    stage[k] = ws->h_desc[desc_off + k];
-                    const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes);
-                    stage[k].block_begin = (uint32_t)blk;
-                    blk += (e - b + qpb - 1) / qpb;
-                }
-                if (blk > 0x7FFFFFFFull) return fail(PM_ERANGE, "launch grid too large");
-                a.total_blocks = (uint32_t)blk;
-                HIPCHK(hipMemcpyAsync(ws->d_desc + desc_off, stage, g.members.size() * sizeof(BatchDesc),
-                                      hipMemcpyHostToDevice, st));
+                // mixed widths: the slice of this query class holds the per-batch workgroup ranges
+                a.batches = ws->d_desc + (size_t)(1 + c) * dcap + desc_off;
+                a.total_blocks = mixed_blocks[(size_t)(&g - groups.data()) * 4 + (size_t)c];
             }
             a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
             a.prune_n = r->nb_best;
             a.bound = g_threshold_bound;
             a.nh = g.nh; a.hits = hb.p; a.hit_count = ws->d_cnt; a.hit_cap = hb.cap;
             a.fetch_count = g_count_fetched ? g_ctx.d_fetch : nullptr; a.fetch_shards = kFetchShards; a.pad_ = 0;
+            a.runs = hb.p + hb.cap; a.run_cap = run_cap_of(hb.cap);
             if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
                 return fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches);
             hipEvent_t es, ee;
@@ -1189,7 +1269,9 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         desc_off += g.members.size();
     }
     HIPCHK(hipEventRecord(r->ev2, st));
-    HIPCHK(hipMemcpyAsync(ws->h_cnt, ws->d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    // counters to the host by a one-thread kernel writing mapped pinned memory: no DMA engine on the
+    // compute stream, so a large D2H of an earlier result (other stream) never delays this search
+    HIPCHK(launch_publish(ws->d_cnt, ws->h_cnt_dev, 4, st));
     HIPCHK(hipEventRecord(ws->done, st));
     r->st.n_queries = nq; r->st.n_terms = q->total_terms;
     r->st.algorithmic_bytes = alg;
@@ -1304,14 +1386,19 @@ extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, ui
     *dptr = r->d_hits; *n = r->n_records;
     return PM_OK;
 }
-extern "C" int pm_result_copy_hits_device(const pm_result_t* r, void* dst, uint64_t capacity) {
+static int ensure_ordered(pm_result* r);
+extern "C" int pm_result_copy_hits_device(pm_result_t* r, void* dst, uint64_t capacity, int ordered) {
     NEED_DEV();
-    if (!r || (!dst && r->n_records)) return fail(PM_EINVAL, "bad argument");
+    if (!r) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
-    if (capacity < r->n_records) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
-                                             (unsigned long long)capacity, (unsigned long long)r->n_records);
-    if (r->n_records) {
-        HIPCHK(hipMemcpyAsync(dst, r->d_hits, r->n_records * sizeof(uint4), hipMemcpyDeviceToDevice, g_ctx.d2h_stream));
+    if (ordered) { int rc = ensure_ordered(r); if (rc) return rc; }
+    const uint64_t n = ordered ? r->n_out : r->n_records;
+    const uint4* src = ordered ? r->d_ord.p : r->d_hits;
+    if (!dst && n) return fail(PM_EINVAL, "bad argument");
+    if (capacity < n) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
+                                  (unsigned long long)capacity, (unsigned long long)n);
+    if (n) {
+        HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(uint4), hipMemcpyDeviceToDevice, g_ctx.d2h_stream));
         HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
     }
     return PM_OK;
@@ -1365,111 +1452,138 @@ extern "C" void pm_hits_sort(pm_hit_t* hits, uint64_t n) {
     if (hits && n) order_hits(hits, n);
 }
 
-// Records as k_scan writes them: runs {count record}{hits, best first, ties by document},
-// one per (query, slot[, column slab / sub-index]) with hits, in arbitrary run order.
-// Orders the RUNS by (slot, query) -- the records inside a run are already in cobs' line
-// order -- and copies them out; the count record of a run that was not cut on the GPU
-// carries no information (its count is the run length) and is dropped.  Several runs of
-// one (slot, query) (rows wider than 1024 bytes, compact sub-indexes) are merged.
-// Returns the number of records written to `out` (<= n), or ~0 when `in` is not a
-// sequence of runs (then the caller falls back to order_hits).
-struct RunRef { uint64_t key, begin; uint32_t len, pad; };
-static uint64_t order_runs(const pm_hit_t* in, uint64_t n, pm_hit_t* out) {
-    if (n == 0) return 0;
-    if (in[0].doc != PM_DOC_COUNT) return ~0ull;
-    std::vector<RunRef> dir;
-    uint64_t i = 0;
-    while (i < n) {
-        uint64_t e = i + 1;
-        while (e < n && in[e].doc != PM_DOC_COUNT) ++e;
-        if (e - i - 1 > 0xFFFFFFFFull) return ~0ull;
-        dir.push_back({((uint64_t)in[i].slot << 32) | in[i].query, i, (uint32_t)(e - i - 1), 0u});
-        i = e;
-    }
-    // order the directory: 16-bit LSD radix over the digits of the key that vary
+// a7 ordering.  k_scan wrote the records as runs {count record}{hits, best first, ties by
+// document}, one per (query, slot[, column slab / sub-index]) with hits, in arbitrary run
+// order, plus a directory entry {query, slot, first record, hits | cut flag} per run.  The
+// records inside a run are already in cobs' line order, so only the RUNS need ordering: the
+// host radix-sorts the directory by (slot, query) (16 bytes per run, not per record), turns
+// it into a copy plan, and k_permute_runs moves every run to its final place in HBM.  The
+// count record of a run that was not cut on the GPU carries no information (its count is
+// the run length) and is dropped.  Several runs of one (slot, query) (rows wider than 1024
+// bytes, compact sub-indexes) are laid out back to back and merged by score on the host.
+struct RunEnt { uint32_t query, slot, begin, len; };      // len bit 31: the list was cut to the n best
+static void sort_directory(std::vector<RunEnt>& dir) {
+    auto key = [](const RunEnt& d) { return ((uint64_t)d.slot << 32) | d.query; };
     if (dir.size() < 2048) {
-        std::sort(dir.begin(), dir.end(), [](const RunRef& a, const RunRef& b) { return a.key != b.key ? a.key < b.key : a.begin < b.begin; });
-    } else {
-        uint64_t varies = 0;
-        for (const RunRef& d : dir) varies |= d.key ^ dir[0].key;
-        std::vector<RunRef> tmp(dir.size());
-        std::vector<uint64_t> cnt(1u << 16);
-        RunRef* src = dir.data(); RunRef* dst = tmp.data();
-        for (int shift = 0; shift < 64; shift += 16) {
-            if (((varies >> shift) & 0xFFFFull) == 0) continue;
-            std::fill(cnt.begin(), cnt.end(), 0);
-            for (size_t k = 0; k < dir.size(); ++k) cnt[(src[k].key >> shift) & 0xFFFFu]++;
-            uint64_t sum = 0;
-            for (auto& c : cnt) { uint64_t t = c; c = sum; sum += t; }
-            for (size_t k = 0; k < dir.size(); ++k) dst[cnt[(src[k].key >> shift) & 0xFFFFu]++] = src[k];
-            std::swap(src, dst);
-        }
-        if (src != dir.data()) memcpy(dir.data(), src, dir.size() * sizeof(RunRef));
+        std::sort(dir.begin(), dir.end(), [&](const RunEnt& a, const RunEnt& b) { return key(a) != key(b) ? key(a) < key(b) : a.begin < b.begin; });
+        return;
     }
+    // begin order first (cheap determinism for several runs of one key), then stable LSD passes on the key digits that vary
+    uint64_t varies = 0;
+    for (const RunEnt& d : dir) varies |= key(d) ^ key(dir[0]);
+    std::vector<RunEnt> tmp(dir.size());
+    std::vector<uint64_t> cnt(1u << 16);
+    RunEnt* src = dir.data(); RunEnt* dst = tmp.data();
+    auto pass = [&](auto digit) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t k = 0; k < dir.size(); ++k) cnt[digit(src[k])]++;
+        uint64_t sum = 0;
+        for (auto& c : cnt) { uint64_t t = c; c = sum; sum += t; }
+        for (size_t k = 0; k < dir.size(); ++k) dst[cnt[digit(src[k])]++] = src[k];
+        std::swap(src, dst);
+    };
+    pass([](const RunEnt& d) { return d.begin & 0xFFFFu; });
+    pass([](const RunEnt& d) { return d.begin >> 16; });
+    for (int shift = 0; shift < 64; shift += 16) {
+        if (((varies >> shift) & 0xFFFFull) == 0) continue;
+        pass([&](const RunEnt& d) { return (uint32_t)((key(d) >> shift) & 0xFFFFu); });
+    }
+    if (src != dir.data()) memcpy(dir.data(), src, dir.size() * sizeof(RunEnt));
+}
+
+static std::mutex g_order_mu;
+static int ensure_ordered_impl(pm_result* r);
+static int ensure_ordered(pm_result* r) { return ensure_ordered_impl(r); }
+static int ensure_ordered_impl(pm_result* r) {
+    if (r->ordered) return PM_OK;
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    if (r->ordered) return PM_OK;
+    r->n_out = 0;
+    r->fixups.clear();
+    if (r->n_records == 0) { r->ordered = true; return PM_OK; }
+    hipStream_t st = g_ctx.d2h_stream;        // never behind the kernels of a later search
+    const uint64_t n_runs = r->n_runs;
+    PinBuf stage{nullptr, 0};
+    { int rc = take_pinned((size_t)n_runs * 2 * sizeof(uint4), &stage); if (rc) return rc; }
+    auto done = [&](int rc) { give_pinned(stage); return rc; };
+#define OCHK(expr)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return done(fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+    RunEnt* h_dir = (RunEnt*)stage.p;
+    uint4* h_plan = (uint4*)stage.p + n_runs;
+    OCHK(hipMemcpyAsync(h_dir, r->d_hits + r->cap, n_runs * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    OCHK(hipStreamSynchronize(st));
+    std::vector<RunEnt> dir(h_dir, h_dir + n_runs);
+    sort_directory(dir);
     uint64_t o = 0;
-    size_t k = 0;
+    size_t np = 0, k = 0;
     while (k < dir.size()) {
         size_t e = k + 1;
-        while (e < dir.size() && dir[e].key == dir[k].key) ++e;
+        while (e < dir.size() && dir[e].slot == dir[k].slot && dir[e].query == dir[k].query) ++e;
         if (e == k + 1) {
-            const RunRef& d = dir[k];
-            if (in[d.begin].score != d.len) out[o++] = in[d.begin];        // cut on the GPU: keep the count
-            memcpy(out + o, in + d.begin + 1, (size_t)d.len * sizeof(pm_hit_t));
-            o += d.len;
+            const RunEnt& d = dir[k];
+            const uint32_t len = d.len & 0x7FFFFFFFu;
+            const bool cut = (d.len >> 31) != 0;             // cut on the GPU: the count record stays
+            const uint32_t n = len + (cut ? 1u : 0u);
+            h_plan[np++] = make_uint4(d.begin + (cut ? 0u : 1u), (uint32_t)o, n, 0u);
+            o += n;
         } else {
-            // several runs of one (slot, query): their hits interleave by score
-            const uint64_t first = o;
+            const uint64_t first = o;                        // several runs of one (slot, query)
             for (size_t j = k; j < e; ++j) {
-                memcpy(out + o, in + dir[j].begin + 1, (size_t)dir[j].len * sizeof(pm_hit_t));
-                o += dir[j].len;
+                const uint32_t len = dir[j].len & 0x7FFFFFFFu;
+                h_plan[np++] = make_uint4(dir[j].begin + 1u, (uint32_t)o, len, 0u);
+                o += len;
             }
-            std::sort(out + first, out + o, hit_less);
+            r->fixups.push_back({first, o});
         }
         k = e;
     }
-    return o;
+    r->n_out = o;
+    { int rc = take_hit_buffer(std::max<uint64_t>(std::max<uint64_t>(o, 2 * (uint64_t)np), 1), &r->d_ord); if (rc) return done(rc); }
+    // the plan travels in the (unused) directory part of the destination buffer
+    uint4* d_plan = r->d_ord.p + r->d_ord.cap;
+    if (np > run_cap_of(r->d_ord.cap)) return done(fail(PM_EHIP, "run directory larger than its bound"));
+    OCHK(hipMemcpyAsync(d_plan, h_plan, np * sizeof(uint4), hipMemcpyHostToDevice, st));
+    OCHK(launch_permute_runs(d_plan, (uint32_t)np, r->d_hits, r->d_ord.p, st));
+    OCHK(hipStreamSynchronize(st));
+    // groups merged from several runs: interleave by score on the host, write back
+    for (auto& f : r->fixups) {
+        std::vector<pm_hit_t> tmp((size_t)(f.second - f.first));
+        OCHK(hipMemcpy(tmp.data(), r->d_ord.p + f.first, tmp.size() * sizeof(pm_hit_t), hipMemcpyDeviceToHost));
+        std::sort(tmp.begin(), tmp.end(), hit_less);
+        OCHK(hipMemcpy(r->d_ord.p + f.first, tmp.data(), tmp.size() * sizeof(pm_hit_t), hipMemcpyHostToDevice));
+    }
+#undef OCHK
+    r->ordered = true;
+    return done(PM_OK);
 }
 
-// D2H of the raw records into the pinned staging buffer (grow-only), on a stream of its own so
-// that the copy never queues behind the kernels of a later search
-static int fetch_records(const pm_result* r, const pm_hit_t** staged) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (g_ctx.h_stage_cap < r->n_records) {
-        if (g_ctx.h_stage) hipHostFree(g_ctx.h_stage);
-        g_ctx.h_stage = nullptr; g_ctx.h_stage_cap = 0;
-        const uint64_t cap = std::max<uint64_t>(r->n_records + r->n_records / 4, 1u << 16);
-        HIPCHK(hipHostMalloc((void**)&g_ctx.h_stage, cap * sizeof(pm_hit_t), hipHostMallocDefault));
-        g_ctx.h_stage_cap = cap;
-    }
-    HIPCHK(hipMemcpyAsync(g_ctx.h_stage, r->d_hits, r->n_records * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.d2h_stream));
-    HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
-    *staged = g_ctx.h_stage;
-    return PM_OK;
-}
-static int records_to_host(const pm_result* r, pm_hit_t* out, uint64_t* n_out) {
-    *n_out = 0;
-    if (r->n_records == 0) return PM_OK;
-    const pm_hit_t* staged = nullptr;
-    { int rc = fetch_records(r, &staged); if (rc) return rc; }
-    uint64_t n = order_runs(staged, r->n_records, out);
-    if (n == ~0ull) {                                  // not a run stream: order the records themselves
-        memcpy(out, staged, (size_t)r->n_records * sizeof(pm_hit_t));
-        order_hits(out, r->n_records);
-        n = r->n_records;
-    }
-    *n_out = n;
-    return PM_OK;
-}
-
-extern "C" int pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity, uint64_t* n_out) {
+extern "C" int pm_result_ordered_device(pm_result_t* r, const void** dptr, uint64_t* n) {
     NEED_DEV();
+    if (!r || !dptr || !n) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
+    { int rc = ensure_ordered(r); if (rc) return rc; }
+    *dptr = r->d_ord.p; *n = r->n_out;
+    return PM_OK;
+}
+
+extern "C" int pm_result_hits_into(const pm_result_t* r_, pm_hit_t* out, uint64_t capacity, uint64_t* n_out) {
+    NEED_DEV();
+    pm_result_t* r = const_cast<pm_result_t*>(r_);
     if (!r || !n_out) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
-    if (!out && r->n_records) return fail(PM_EINVAL, "bad argument");
-    if (capacity < r->n_records) return fail(PM_EINVAL, "destination holds %llu records, need up to %llu",
-                                             (unsigned long long)capacity, (unsigned long long)r->n_records);
-    return records_to_host(r, out, n_out);
+    { int rc = ensure_ordered(r); if (rc) return rc; }
+    if (!out && r->n_out) return fail(PM_EINVAL, "bad argument");
+    if (capacity < r->n_out) return fail(PM_EINVAL, "destination holds %llu records, need %llu",
+                                         (unsigned long long)capacity, (unsigned long long)r->n_out);
+    if (r->n_out) {
+        HIPCHK(hipMemcpyAsync(out, r->d_ord.p, r->n_out * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.d2h_stream));
+        HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
+    }
+    *n_out = r->n_out;
+    return PM_OK;
 }
 
 extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {
@@ -1477,14 +1591,15 @@ extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64
     if (!r || !hits || !n) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
     if (!r->host_ready) {
-        r->host.resize((size_t)r->n_records);
-        uint64_t got = 0;
-        int rc = records_to_host(r, r->host.data(), &got);
-        if (rc) return rc;
-        r->host.resize((size_t)got);
+        { int rc = ensure_ordered(r); if (rc) return rc; }
+        { int rc = take_pinned((size_t)r->n_out * sizeof(pm_hit_t), &r->host); if (rc) return rc; }
+        if (r->n_out) {
+            HIPCHK(hipMemcpyAsync(r->host.p, r->d_ord.p, r->n_out * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.d2h_stream));
+            HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
+        }
         r->host_ready = true;
     }
-    *hits = r->host.data(); *n = r->host.size();
+    *hits = (const pm_hit_t*)r->host.p; *n = r->n_out;
     return PM_OK;
 }
 extern "C" void pm_result_free(pm_result_t* r) {

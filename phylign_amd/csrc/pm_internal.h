@@ -49,6 +49,8 @@ struct ScanArgs {
     unsigned long long* fetch_count;   // null, or fetch_shards counters of gathered algorithmic bytes
     uint32_t        fetch_shards;      // power of two
     uint32_t        pad_;
+    uint4*          runs;       // run directory {query, slot, first record, hits | cut flag << 31}
+    uint64_t        run_cap;
 };
 
 // launchers (pm_kernels.hip); all asynchronous on `st`, return hipError_t
@@ -71,6 +73,8 @@ hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, ui
                                 const uint64_t* hashes, const QDesc* qd, uint32_t nh,
                                 uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms,
                                 uint64_t seed, hipStream_t st);
+hipError_t launch_publish(const unsigned long long* src, unsigned long long* dst_mapped, int n, hipStream_t st);
+hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* src, uint4* dst, hipStream_t st);
 hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
                         uint64_t n, hipStream_t st);
 

@@ -462,16 +462,25 @@ __global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs 
     }
     const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
     const unsigned long long lead_bal = __ballot(leader);
-    unsigned long long basev = 0;
+    unsigned long long basev = 0, baser = 0;
     if (lane == 0) {
         basev = atomicAdd(a.hit_count, (unsigned long long)wave_total);
-        atomicAdd(a.hit_count + 1, (unsigned long long)__popcll(lead_bal));
+        baser = atomicAdd(a.hit_count + 1, (unsigned long long)__popcll(lead_bal));
     }
     const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)basev, 0, 64);
     const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(basev >> 32), 0, 64);
+    const uint32_t rlo = (uint32_t)__shfl((int)(uint32_t)baser, 0, 64);
+    const uint32_t rhi = (uint32_t)__shfl((int)(uint32_t)(baser >> 32), 0, 64);
     const uint32_t run_off = (uint32_t)__shfl((int)(incl - recs), (int)gfirst, 64);
     const uint64_t run_base = (((uint64_t)bhi << 32) | blo) + run_off;
-    if (leader && run_base < a.hit_cap) a.hits[run_base] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
+    if (leader && run_base < a.hit_cap) {
+        a.hits[run_base] = make_uint4(q, 0xFFFFFFFFu, full_count, bd.slot);
+        // run directory {query, slot, first record, hits | cut flag}: what the host orders instead of records
+        const uint64_t ridx = (((uint64_t)rhi << 32) | rlo) +
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(lead_bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead_bal, 0u));
+        if (ridx < a.run_cap)
+            a.runs[ridx] = make_uint4(q, bd.slot, (uint32_t)run_base, total | (full_count != total ? 0x80000000u : 0u));
+    }
 
     u32x4 R = mask;
     uint32_t emitted = 0;
@@ -771,6 +780,36 @@ hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, ui
     if (blocks > 262144) blocks = 262144;
     hipLaunchKernelGGL(k_plant_cluster, dim3((uint32_t)blocks), dim3(256), 0, st, matrix, stride, S, barrett_m(S),
                        n_docs, hashes, qd, nh, q_first, q_step, n_sel, max_terms, seed);
+    return hipGetLastError();
+}
+
+// copies n 64-bit words to device-mapped host memory (record counters of a search)
+__global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* dst, int n) {
+    if ((int)threadIdx.x < n) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_publish(const unsigned long long* src, unsigned long long* dst_mapped, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, src, dst_mapped, n);
+    return hipGetLastError();
+}
+
+// a7 on the device, second half: the host has ordered the run directory by (slot, query);
+// this copies every run to its final place.  plan[i] = {first source record, first
+// destination record, records, -}.  One wavefront per run, 16 bytes per lane.
+__global__ __launch_bounds__(256) void k_permute_runs(const uint4* __restrict__ plan, uint32_t n_plan,
+                                                       const uint4* __restrict__ src, uint4* __restrict__ dst)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * 4u;
+    for (uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6); e < n_plan; e += waves) {
+        const uint4 p = plan[e];
+        for (uint32_t i = lane; i < p.z; i += 64u) dst[(uint64_t)p.y + i] = src[(uint64_t)p.x + i];
+    }
+}
+hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* src, uint4* dst, hipStream_t st) {
+    if (n_plan == 0) return hipSuccess;
+    uint32_t blocks = (n_plan + 3u) / 4u;
+    if (blocks > 65536u) blocks = 65536u;
+    hipLaunchKernelGGL(k_permute_runs, dim3(blocks), dim3(256), 0, st, plan, n_plan, src, dst);
     return hipGetLastError();
 }
 

@@ -86,6 +86,13 @@ def test_device_records_are_ordered_runs(pm, oracle):
         assert pm.format_hits(ix, q, host, slot=6, nb_best_hits=n if n else -1) == \
             pm.format_hits(ix, q, raw, slot=6, nb_best_hits=n if n else -1)   # raw runs format the same
         assert np.array_equal(pm.sort_hits(host.copy()), host)
+        # the ordered form in HBM (what RCCL sends) is what the host sees
+        dptr, n_out = res.ordered_device()
+        assert n_out == len(host) and dptr
+        buf2 = torch.zeros((n_out, 4), dtype=torch.int32, device="cuda")
+        res.copy_hits_device(buf2.data_ptr(), n_out, ordered=True)
+        assert np.array_equal(buf2.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1), host)
+        assert np.array_equal(res.hits(copy=False), host)
 
 
 def test_searches_in_flight_give_the_same_records(pm, oracle):

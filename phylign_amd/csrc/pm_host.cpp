@@ -21,6 +21,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unistd.h>
 #include <vector>
@@ -1625,23 +1626,16 @@ static inline void append_tab_uint_nl(std::string& out, uint64_t v) {     // "\t
     out.push_back('\n');
 }
 
-extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
-                              const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
-                              int64_t nb_best, char** text, size_t* len) {
-    if (!ix || !q || (!hits && n_hits) || !text || !len) return fail(PM_EINVAL, "bad argument");
-    const size_t nq = q->headers.size();
-    std::vector<pm_hit_t> mine;
-    for (uint64_t i = 0; i < n_hits; ++i) if (hits[i].slot == slot) mine.push_back(hits[i]);
-    for (const pm_hit_t& h : mine)
-        if (h.query >= nq || (h.doc >= ix->info.n_docs && h.doc != PM_DOC_COUNT))
-            return fail(PM_EINVAL, "hit record (query %u, doc %u) out of range for this index/query set", h.query, h.doc);
-    order_hits(mine.data(), mine.size());
-    std::string out;
-    out.reserve(mine.size() * 28 + nq * 24);
-    size_t p = 0;
-    for (size_t qi = 0; qi < nq; ++qi) {
+// formats the records of queries [qa, qb) (a slice of one slot's ordered records) into `out`;
+// returns PM_OK or an error code with the message in `err`
+static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_hit_t* mine, size_t n_mine,
+                              size_t qa, size_t qb, int64_t nb_best, std::string& out, std::string& err) {
+    char msg[512];
+    size_t p = (size_t)(std::lower_bound(mine, mine + n_mine, (uint32_t)qa,
+                                         [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
+    for (size_t qi = qa; qi < qb; ++qi) {
         size_t e = p;
-        while (e < mine.size() && mine[e].query == qi) ++e;
+        while (e < n_mine && mine[e].query == qi) ++e;
         size_t total = e - p;
         if (p < e && mine[p].doc == PM_DOC_COUNT) {
             // count records lead the run: cut on the GPU (one record: the number of documents that
@@ -1650,12 +1644,20 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
             while (p < e && mine[p].doc == PM_DOC_COUNT) { total += mine[p].score; ++p; }
         }
         if (!q->headerless[qi]) out.push_back('*');
-        else if (nb_best >= 0)      // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
-            return fail(PM_EINVAL, "record %zu has sequence lines before any FASTA header: the post-filter cannot parse its result", qi);
+        else if (nb_best >= 0) {    // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
+            snprintf(msg, sizeof msg, "record %zu has sequence lines before any FASTA header: the post-filter cannot parse its result", qi);
+            err = msg;
+            return PM_EINVAL;
+        }
         out += q->headers[qi];
         append_tab_uint_nl(out, total);
         uint32_t min_kmers = 0;
         for (size_t i = p; i < e; ++i) {
+            if (mine[i].doc >= ix->info.n_docs) {
+                snprintf(msg, sizeof msg, "hit record (query %u, doc %u) out of range for this index", mine[i].query, mine[i].doc);
+                err = msg;
+                return PM_EINVAL;
+            }
             const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
             const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
             if (nb_best < 0) {
@@ -1669,7 +1671,9 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
                 // postprocess_cobs.py:16-18 turns such a line into a bare "_" (no newline) and
                 // raises on int("_") once rank >= n: an error for the whole rule
                 if (rank < nb_best) { out.push_back('_'); continue; }
-                return fail(PM_EINVAL, "document name '%.*s' has no '_' separator (post-filter cannot parse it)", (int)nl, nm);
+                snprintf(msg, sizeof msg, "document name '%.*s' has no '_' separator (post-filter cannot parse it)", (int)nl, nm);
+                err = msg;
+                return PM_EINVAL;
             }
             bool keep;
             if (rank < nb_best) keep = true;
@@ -1682,10 +1686,71 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
         }
         p = e;
     }
-    char* buf = (char*)malloc(out.size() + 1);
+    return PM_OK;
+}
+
+extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
+                              const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                              int64_t nb_best, char** text, size_t* len) {
+    if (!ix || !q || (!hits && n_hits) || !text || !len) return fail(PM_EINVAL, "bad argument");
+    const size_t nq = q->headers.size();
+    // records as pm_result_hits_* deliver them are already in line order: the slot's records are
+    // one contiguous slice; anything else (gathered, hand-made) is copied and ordered first
+    std::vector<pm_hit_t> copy;
+    const pm_hit_t* mine = hits;
+    size_t n_mine = 0;
+    if (std::is_sorted(hits, hits + n_hits, [](const pm_hit_t& a, const pm_hit_t& b) { return hit_less(a, b); })) {
+        const pm_hit_t* lo = std::lower_bound(hits, hits + n_hits, slot, [](const pm_hit_t& h, uint32_t v) { return h.slot < v; });
+        const pm_hit_t* hi = std::upper_bound(lo, hits + n_hits, slot, [](uint32_t v, const pm_hit_t& h) { return v < h.slot; });
+        mine = lo; n_mine = (size_t)(hi - lo);
+    } else {
+        for (uint64_t i = 0; i < n_hits; ++i) if (hits[i].slot == slot) copy.push_back(hits[i]);
+        order_hits(copy.data(), copy.size());
+        mine = copy.data(); n_mine = copy.size();
+    }
+    if (n_mine && mine[n_mine - 1].query >= nq)
+        return fail(PM_EINVAL, "hit record (query %u) out of range for this query set", mine[n_mine - 1].query);
+    // query ranges are independent: format them on several host threads (at 1 M queries a single
+    // thread spends seconds per batch here, scripts/postprocess_cobs.py far more)
+    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), (nq + n_mine / 8) / 4096);
+    if (nt < 1) nt = 1;
+    std::vector<std::string> parts(nt), errs(nt);
+    std::vector<int> rcs(nt, PM_OK);
+    // split by records + queries so that long hit lists spread evenly
+    std::vector<size_t> cutq(nt + 1, nq);
+    cutq[0] = 0;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t target = (n_mine + nq) * t / nt;          // position in the merged (records + headers) stream
+        size_t lo = cutq[t - 1], hi = nq;                        // smallest query whose prefix weight reaches target
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            const size_t recs = (size_t)(std::lower_bound(mine, mine + n_mine, (uint32_t)mid,
+                                                          [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
+            if (recs + mid < target) lo = mid + 1; else hi = mid;
+        }
+        cutq[t] = lo;
+    }
+    auto work = [&](size_t t) {
+        parts[t].reserve((size_t)((double)(n_mine * 28 + nq * 24) / (double)nt * 1.1) + 64);
+        rcs[t] = format_query_range(ix, q, mine, n_mine, cutq[t], cutq[t + 1], nb_best, parts[t], errs[t]);
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (size_t t = 0; t < nt; ++t)
+        if (rcs[t] != PM_OK) return fail(rcs[t], "%s", errs[t].c_str());      // the first failing query range, as a serial pass would report
+    size_t total = 0;
+    for (auto& s2 : parts) total += s2.size();
+    char* buf = (char*)malloc(total + 1);
     if (!buf) return fail(PM_ENOMEM, "out of host memory");
-    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
-    *text = buf; *len = out.size();
+    size_t o = 0;
+    for (auto& s2 : parts) { memcpy(buf + o, s2.data(), s2.size()); o += s2.size(); }
+    buf[total] = 0;
+    *text = buf; *len = total;
     return PM_OK;
 }
 

@@ -47,10 +47,18 @@ def scale_shapes(shapes, rows_divisor):
                        index_bytes=max(1024, s.signature_size // rows_divisor) * s.row_bytes) for s in shapes]
 
 
+# measured scan time per looked-up row by 128-byte lines per row, relative to one line of a 4-line row
+# (tools/per_batch_cost.py on one MI355X, 12 M lookups per batch, fetch-all scan; profiles/r02/per_batch_cost.tsv):
+# 0.28 / 0.54 / 0.84 / 1.03 ms for 1 / 2 / 3 / 4 lines
+_LINE_COST = {1: 109, 2: 210, 3: 327, 4: 400}
+
+
 def scan_cost(shape):
     """relative scan cost of one query k-mer against this batch: HBM moves whole
-    128-byte lines, so a row costs its width rounded up to lines"""
-    return (shape.row_bytes + 127) // 128 * 128
+    128-byte lines, so a row costs its width rounded up to lines,
+    weighted by the measured per-line cost of that row width"""
+    lines = (shape.row_bytes + 127) // 128
+    return _LINE_COST.get(lines, 100 * lines)
 
 
 def assign_batches(shapes, n_ranks, capacity_bytes=None):

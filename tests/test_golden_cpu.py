@@ -421,3 +421,41 @@ def test_fasta_record_rules_property(oracle):
             got = None
         assert got == exp, fa
     check()
+
+
+def test_native_postfilter_many_queries_threads_and_order_paths():
+    """pm_format_hits on enough queries for its multi-threaded path, on ordered records (sliced in
+    place) and on shuffled ones (copied and ordered), against the golden-pinned Python mirror"""
+    from phylign_amd import _lib as pm
+    from phylign_amd import postprocess as P
+    rng = np.random.default_rng(4)
+    nq, n_docs = 30000, 500
+    names = [f"{rng.integers(0, 16**5):05x}_SAM{d:05d}" for d in range(n_docs)]
+    fasta = "".join(f">q{i} c{i % 7}\nACGTACGTACGTACGTACGTACGTACGTACGTA\n" for i in range(nq)).encode()
+    recs, lines = [], []
+    for qi in range(nq):
+        k = int(rng.integers(0, 12)) if qi % 50 else 300
+        docs = rng.choice(n_docs, size=k, replace=False)
+        scores = rng.integers(1, 4, size=k)
+        order = sorted(range(k), key=lambda j: (-int(scores[j]), int(docs[j])))
+        lines.append(f"*q{qi} c{qi % 7}\t{k}\n")
+        for j in order:
+            recs.append((qi, int(docs[j]), int(scores[j]), 3))
+            lines.append(f"{names[docs[j]]}\t{int(scores[j])}\n")
+    text = "".join(lines)
+    hits = np.array(recs, dtype=pm.HIT_DTYPE)
+    q = pm.Queries(fasta, term_size=31)
+    ix = pm.Index.from_names(names)
+    other = hits.copy()
+    other["slot"] = 9                                    # records of another slot around it
+    both = np.concatenate([hits, other])
+    shuffled = both[rng.permutation(len(both))]
+    for n in (-1, 1, 2, 100):
+        want = text if n < 0 else P.filter_text(text, n)
+        assert pm.format_hits(ix, q, both, slot=3, nb_best_hits=n).decode() == want
+        assert pm.format_hits(ix, q, shuffled, slot=3, nb_best_hits=n).decode() == want
+    assert pm.format_hits(ix, q, both, slot=5).decode() == "".join(f"*q{i} c{i % 7}\t0\n" for i in range(nq))
+    bad = hits.copy()
+    bad["doc"][len(bad) // 2] = n_docs + 5
+    with pytest.raises(pm.PMError):
+        pm.format_hits(ix, q, bad, slot=3)

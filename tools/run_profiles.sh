@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Round profile set on the GPU box (run from the repo root through gpurun):
+#   bash tools/run_profiles.sh r02
+# -> gpurun_out/prof_<tag>/{fetch_all,bound}/ kernel traces with --stats, the bench line of each run,
+#    and the PMC passes of tools/run_pmc.sh for both scan modes.
+set -u
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/fetch_all -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --only-headline > $out/bench_fetch_all.json 2> $out/bench_fetch_all.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bound -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --only-headline --headline threshold_bound > $out/bench_bound.json 2> $out/bench_bound.log
+bash tools/run_pmc.sh ${tag}
+PMC_BENCH_FLAGS="--headline threshold_bound" bash tools/run_pmc.sh ${tag}_bound
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag}/fetch gpurun_out/pmc_${tag}/rdreq gpurun_out/pmc_${tag}/write > $out/pmc_fetch_all.txt
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag}_bound/fetch gpurun_out/pmc_${tag}_bound/rdreq gpurun_out/pmc_${tag}_bound/write > $out/pmc_bound.txt
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag}/calib_fetch gpurun_out/pmc_${tag}/calib_rdreq gpurun_out/pmc_${tag}/calib_write > $out/pmc_calibration.txt
+find $out -name "*stats*.csv" | head
+# drop the bulky per-dispatch traces, keep the summaries
+find gpurun_out/pmc_${tag} gpurun_out/pmc_${tag}_bound -name "*.csv" -size +2M -delete

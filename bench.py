@@ -45,13 +45,33 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def effective_cpus():
+    """CPUs this process may really use: the scheduler affinity, capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants the job a 16-CPU quota: 256 threads would
+    only be throttled)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(np.ceil(quota / period))))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
     """Times oracle/cobs_oracle.c (kind "port": a restatement of the cobs classic
     search, NOT bioconda cobs 0.2.1) on the host cores: same document counts per
     batch (same algorithmic bytes per k-mer), rows scaled down to fit host RAM."""
     from oracle import oracle as O
     from phylign_amd import workload as W
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     total = sum(s.index_bytes for s in shapes)
     div = max(1, int(np.ceil(total / (sample_gb * 1e9))))
     small = W.scale_shapes(shapes, div)
@@ -86,6 +106,7 @@ def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
     log(f"[cpu_baseline] gen {t_gen:.1f}s, {nq} queries in {tt:.2f}s on {cores} threads")
     return {
         "value": terms / tt, "unit": "k-mers/s", "cores": cores, "kind": "port",
+        "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity / cgroup quota): {cores} threads",
         "sample": (f"{nq} of the same queries x all {len(shapes)} batch shapes with rows/{div} "
                    f"({sum(s.index_bytes for s in small) / 1e9:.2f} GB resident in host RAM), "
                    f"{tt:.1f}s wall, oracle/cobs_oracle.c COBS-restatement (not bioconda cobs 0.2.1)"),
@@ -111,6 +132,9 @@ def main():
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the other scan mode, the clustered variant and the fetched-bytes pass (profiling runs)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered (home batch) variant")
+    ap.add_argument("--clustered-multi", action="store_true",
+                    help="run the clustered variant with N > 1 too (it ships ~0.5 GB of records per step to rank 0; "
+                         "by default it is a single-GPU figure)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queueing the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=12.0)
@@ -390,7 +414,7 @@ def main():
 
     # ---- clustered variant: every query gets a home batch (changes the resident matrices: last)
     clustered = None
-    if full and not args.no_clustered:
+    if full and not args.no_clustered and (world == 1 or args.clustered_multi):
         t0 = time.time()
         for pos, ix in zip(mine, indexes):
             ix.plant_cluster(q, pos, len(shapes), seed=97)

@@ -225,7 +225,30 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     env2 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2"] + common + ["--dump-hits", str(two)], capture_output=True, env=env2)
+                        "--gpus", "2", "--clustered-multi"] + common + ["--dump-hits", str(two)], capture_output=True, env=env2)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     a, b = np.load(one), np.load(two)
     assert len(a) > 50 and np.array_equal(a, b)
+
+
+def test_hit_buffer_overflow_reruns_with_the_exact_size(pm, oracle):
+    """more records than the first hit buffer holds (threshold 0: every document of every query):
+    the search is queued again with a buffer of the exact size; later searches size theirs from it"""
+    rng = np.random.default_rng(82)
+    n_docs, S, nq = 4000, 1500, 300
+    queries = [(f"o{i}", rand_seq(rng, 40)) for i in range(nq)]
+    index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, density=0.3)
+    ix = pm.Index.load_mem(index)
+    q = pm.Queries(fasta)
+    exp = oracle.query_file(index, fasta, 0.0)
+    for _ in range(2):
+        res = pm.search([ix], q, 0.0)
+        st = res.stats
+        assert st.n_hits == nq * n_docs and st.n_runs == nq and st.n_records == nq * (n_docs + 1) > (1 << 20)
+        hits = res.hits()
+        assert len(hits) == nq * n_docs                       # no list was cut: no count records on the host
+        assert pm.format_hits(ix, q, hits) == exp
+    a = pm.search_async([ix], q, 0.0)
+    b = pm.search_async([ix], q, 0.0, nb_best_hits=5)
+    assert pm.format_hits(ix, q, b.hits(), nb_best_hits=5) == pm.query_text(ix, fasta, 0.0, nb_best_hits=5)
+    assert pm.format_hits(ix, q, a.hits()) == exp

@@ -180,6 +180,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
+    if os.environ.get("PM_SINGLE_LAUNCH"):
+        pm.set_option("single_launch", 1)
     dev = pm.device_info()
     log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
 

@@ -146,6 +146,8 @@ static const int kPlaneClass[4] = {7, 10, 16, 24};
 static uint32_t g_threshold_bound = 1;
 // pm_set_option("count_fetched"): the scan also counts the algorithmic bytes it really gathered
 static uint32_t g_count_fetched = 0;
+// pm_set_option("single_launch"): every row width (up to 1024 B) goes into the mixed-width launch
+static uint32_t g_single_launch = 0;
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
@@ -213,6 +215,7 @@ extern "C" int pm_set_option(const char* name, int64_t value) {
     if (!name) return fail(PM_EINVAL, "bad argument");
     if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "count_fetched") == 0) { g_count_fetched = value ? 1u : 0u; return PM_OK; }
+    if (strcmp(name, "single_launch") == 0) { g_single_launch = value ? 1u : 0u; return PM_OK; }
     return fail(PM_EINVAL, "unknown option '%s'", name);
 }
 
@@ -1110,7 +1113,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     std::vector<Group> groups;
     for (size_t u = 0; u < units.size(); ++u) {
         const pm_index* ix = units[u].ix;
-        const int key = (ix->slabs == 1 && ix->g < 32) ? 0 : ix->g;
+        const int key = (ix->slabs == 1 && (ix->g < 32 || g_single_launch)) ? 0 : ix->g;
         Group* gp = nullptr;
         if (ix->slabs == 1)
             for (auto& g : groups)

@@ -164,13 +164,13 @@ def main(argv=None):
         admit.release(need - held)                      # keep only what the matrix really occupies
         return pos, ix, held, time.time() - t0
 
+    from . import pgzip
     writers = ThreadPoolExecutor(max_workers=4)
+    deflaters = ThreadPoolExecutor(max_workers=max(2, min(16, len(os.sched_getaffinity(0)))))
 
     def write_gz(path, text):
-        tmp = path + ".tmp"
-        with gzip.open(tmp, "wb", compresslevel=1) as g:            # `gzip --fast` (Snakefile:468)
-            g.write(text)
-        os.replace(tmp, path)                                       # never leave a partial file that looks complete
+        # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
+        pgzip.write(path, text, level=1, pool=deflaters)
 
     kept, names_of, log_rows, pending = [], {}, [], []
     nb = args.nb_best_hits
@@ -201,6 +201,7 @@ def main(argv=None):
     for p in pending:
         p.result()
     writers.shutdown()
+    deflaters.shutdown()
 
     # ---- 04_filter: gather the pruned records (and names) to rank 0, merge natively
     if args.filter_out:

@@ -459,3 +459,24 @@ def test_native_postfilter_many_queries_threads_and_order_paths():
     bad["doc"][len(bad) // 2] = n_docs + 5
     with pytest.raises(pm.PMError):
         pm.format_hits(ix, q, bad, slot=3)
+
+
+def test_parallel_gzip_members_decode_like_gzip_fast(tmp_path):
+    """03_match container (a9): multi-member gzip written on a thread pool decodes to the same
+    bytes with Python's gzip (what xopen uses in scripts/filter_queries.py) and the gzip CLI"""
+    import gzip
+    import subprocess
+    from phylign_amd import pgzip
+    rng = np.random.default_rng(6)
+    lines = [b"*q%d\t%d\n" % (i, i % 7) + b"".join(b"_SAM%06d\t%d\n" % (int(d), 90 + int(d) % 30) for d in rng.integers(0, 10**6, size=i % 40))
+             for i in range(60000)]
+    text = b"".join(lines)
+    assert len(text) > 3 * pgzip.CHUNK
+    parts = pgzip.split_lines(text)
+    assert b"".join(parts) == text and len(parts) > 3 and all(p.endswith(b"\n") for p in parts)
+    for payload in (text, b"", b"*only\t0\n"):
+        p = tmp_path / "x.gz"
+        pgzip.write(str(p), payload)
+        assert gzip.open(p, "rb").read() == payload
+        assert subprocess.run(["gzip", "-dc", str(p)], capture_output=True, check=True).stdout == payload
+        assert not (tmp_path / "x.gz.tmp").exists()

@@ -171,3 +171,53 @@ def test_config1_bundled_reads_on_batches_small_shapes(pm, oracle, tmp_path):
         got = pm.search([ix], q, 0.7, slot_base=pos, nb_best_hits=1)
         assert pm.format_hits(ix, q, got.hits(), slot=pos, nb_best_hits=1).decode() == want
         ix.free()
+
+
+def test_config5_one_million_queries_on_one_rank_shard(pm, oracle):
+    """BASELINE configs[4] asks for 1 M queries: the query count at full size against the shard one
+    rank of an 8-way split of config 3 holds (~27 GB), pipelined like the stage drives it.  Checks:
+    exact parity on sampled queries against the oracle on the virtual matrix, planted totals, and
+    that a query's records do not depend on the query set it travels in (first 50 k alone)."""
+    shapes = W.select("config3")
+    mine = W.assign_batches(shapes, 8)[3]
+    nq = 1_000_000
+    fasta, seqs = W.make_queries(nq, 150, seed=5)
+    q = pm.Queries(fasta)
+    assert q.count() == (nq, nq * 120)
+    hashes = q.hash_terms(1, 1)
+    sub = [shapes[p] for p in mine]
+    plan, sure = W.plant_plan(hashes, nq, 120, sub, every=5000)
+    del hashes
+    ixs = []
+    for i, s in enumerate(sub):
+        ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, seed=SEED)
+        if i in plan:
+            ix.plant(*plan[i])
+        ixs.append(ix)
+    a = pm.search_async(ixs, q, 0.7, nb_best_hits=100)
+    b = pm.search_async(ixs, q, 0.7, nb_best_hits=100)           # two searches of a million queries in flight
+    hits = a.hits()
+    st = a.stats
+    assert st.algorithmic_bytes == nq * 120 * sum(s.row_bytes for s in sub)
+    real = hits[hits["doc"] != pm.PM_DOC_COUNT]
+    assert len(real) >= sure
+    assert np.array_equal(b.hits(), hits)
+    checked = 0
+    for i, s in enumerate(sub):
+        planted = [qq for n, qq in enumerate(range(0, nq, 5000)) if n % len(sub) == i][:2]
+        sample = sorted(set(planted + [i * 7919 + 3, nq - 1 - i]))
+        ov = _overlay(*plan[i]) if i in plan else {}
+        exp = _expected_hits(oracle, s, seqs, sample, ov, 0.7)
+        sel = real[(real["slot"] == i) & np.isin(real["query"], sample)]
+        assert [(int(x["query"]), int(x["doc"]), int(x["score"])) for x in sel] == exp, s.batch
+        checked += len(exp)
+    assert checked >= len(sub) * 2 * 4
+    # the same first 50 000 queries as a query set of their own
+    cut = fasta.index(b">q0050000\n")
+    q50 = pm.Queries(fasta[:cut])
+    assert q50.count()[0] == 50000
+    small = pm.search(ixs, q50, 0.7, nb_best_hits=100).hits()
+    assert np.array_equal(small, hits[hits["query"] < 50000])
+    # text of one batch at this size: every query gets its header line
+    text = pm.format_hits(ixs[0], q, hits, slot=0, nb_best_hits=100)
+    assert text.count(b"*q") == nq

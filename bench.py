@@ -228,6 +228,9 @@ def main():
             torch.cuda.synchronize()
 
     pg_dev = "cuda" if backend == "nccl" else "cpu"
+    # BENCH_FORCE_GATHER=1: a single rank walks the device-tensor gather path of the N>1 runs (D2D copy of the
+    # ordered records into the packed tensor, rank-0 read-back) without a collective -- functional check
+    force_gather = bool(os.environ.get("BENCH_FORCE_GATHER"))
     packed = PackedGather(1 << 16, pg_dev)          # 64 Ki records (1 MiB) per rank in one collective
     last = {}
     kept = []        # results whose pinned records are still referenced (freed at the end)
@@ -248,7 +251,7 @@ def main():
         # orders the run directory, k_permute_runs moves the runs); ranks own disjoint, increasing slot
         # ranges, so the rank-order concatenation that the gather produces on rank 0 is globally ordered
         host = None
-        if world == 1:
+        if world == 1 and not force_gather:
             host = res.hits(copy=False)                    # view of the library's pinned buffer (lives as long as `res`)
             t_c = time.perf_counter()
         elif pg_dev == "cuda":

@@ -103,7 +103,12 @@ _lib = None
 
 
 def load():
-    """dlopen the HIP library; raises (never falls back) when it is missing."""
+    """dlopen the HIP library; raises (never falls back) when it is missing.
+
+    A process that also drives the GPU through torch (bench.py, the multi-rank match_stage)
+    must `import torch` BEFORE the first call of this function: the torch wheel bundles its own
+    libamdhip64 under the same SONAME as /opt/rocm's, the dynamic loader keeps whichever came
+    first for both users, and torch finds no GPU on the other one."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

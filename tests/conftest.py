@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before libphylign_match.so: torch bundles its own libamdhip64 with the same SONAME as
+#                              /opt/rocm's; whichever is loaded first serves both, and torch only finds GPUs with its own
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -55,3 +55,44 @@ def test_random_case_text_identical(pm, oracle, seed):
     assert pm.query_text(ix, fasta, thr) == exp
     n = int(rng.choice([1, 2, 5, 100]))
     assert pm.query_text(ix, fasta, thr, nb_best_hits=n).decode() == P.filter_text(exp.decode(), n)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_multi_index_search_text_identical(pm, oracle, seed):
+    """several random batches of different row widths in ONE search (fused launches, mixed-width
+    launch, column slabs), dense and sparse hit lists, both scan modes, sync and in flight: the
+    text of every slot equals the oracle's for that index"""
+    from phylign_amd import postprocess as P
+    rng = np.random.default_rng(5000 + seed)
+    nq = int(rng.integers(1, 40))
+    lens = [int(rng.choice([31, 38, 39, 40, 100, 150, 150, 300, 1200])) for _ in range(nq)]
+    queries = [(f"m{i}", rand_seq(rng, lens[i])) for i in range(nq)]
+    thr = float(rng.choice([0.0, 0.3, 0.7, 0.7, 1.0]))
+    n_idx = int(rng.integers(2, 7))
+    cases = []
+    for _ in range(n_idx):
+        n_docs = int(rng.choice([3, 64, 100, 130, 300, 600, 1024, 2100, 4000, 4000, 8300]))
+        S = int(rng.integers(60, 2500))
+        density = float(rng.choice([0.02, 0.25, 0.25, 0.6]))
+        plant = [(int(rng.integers(0, nq)), int(rng.integers(0, n_docs)), float(rng.choice([1.0, 0.9, 0.75, 0.7, 0.69, 0.4])))
+                 for _ in range(int(rng.integers(0, 60)))]
+        cases.append(build_case(oracle, rng, n_docs, S, queries, density=density, plant=plant))
+    fasta = cases[0][1]
+    ixs = [pm.Index.load_mem(c[0], layout=int(rng.integers(0, 3))) for c in cases]
+    q = pm.Queries(fasta)
+    base = int(rng.integers(0, 1000))
+    n = int(rng.choice([0, 1, 3, 100]))
+    exp = [oracle.query_file(c[0], fasta, thr) for c in cases]
+    got = {}
+    for bound in (1, 0):
+        pm.set_option("threshold_bound", bound)
+        r1 = pm.search_async(ixs, q, thr, slot_base=base, nb_best_hits=n)
+        r2 = pm.search_async(ixs, q, thr, slot_base=base)
+        got[bound] = (r1.hits(), r2.hits())
+    pm.set_option("threshold_bound", 1)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    pruned, plain = got[1]
+    for s, ix in enumerate(ixs):
+        assert pm.format_hits(ix, q, plain, slot=base + s) == exp[s]
+        if n:
+            assert pm.format_hits(ix, q, pruned, slot=base + s, nb_best_hits=n).decode() == P.filter_text(exp[s].decode(), n)

@@ -221,6 +221,12 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     assert line["threshold_bound"]["hits_identical_to_headline"] and line["clustered"]["hits_identical"]
     assert line["roofline"]["frac"] < 1.0 and line["threshold_bound"]["roofline"]["frac"] < 1.0
     assert line["clustered"]["fetch_all_rows"]["hits"] > 20 * line["hits"]
+    # the device-tensor gather path of the RCCL runs (D2D copy of the ordered records, read-back), one rank
+    forced = tmp_path / "forced.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(forced), "--no-clustered"],
+                       capture_output=True, env=dict(env, BENCH_FORCE_GATHER="1"))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert np.array_equal(np.load(one), np.load(forced))
     two = tmp_path / "two.npy"
     env2 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -1496,9 +1496,7 @@ static void sort_directory(std::vector<RunEnt>& dir) {
 }
 
 static std::mutex g_order_mu;
-static int ensure_ordered_impl(pm_result* r);
-static int ensure_ordered(pm_result* r) { return ensure_ordered_impl(r); }
-static int ensure_ordered_impl(pm_result* r) {
+static int ensure_ordered(pm_result* r) {
     if (r->ordered) return PM_OK;
     std::lock_guard<std::mutex> lk(g_order_mu);
     if (r->ordered) return PM_OK;

@@ -35,3 +35,52 @@ def build_case(O, rng, n_docs, sig_size, queries, k=31, canon=1, num_hashes=1,
     index = O.make_index(k, canon, sig_size, num_hashes, names, matrix)
     fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
     return index, fasta, matrix
+
+
+# ---------------------------------------------------------------- genome-like batches
+def mutate(rng, seq_codes, rate):
+    """substitutions at `rate` per base on a uint8 code array (0..3)"""
+    out = seq_codes.copy()
+    pos = np.flatnonzero(rng.random(out.size) < rate)
+    out[pos] = (out[pos] + rng.integers(1, 4, size=pos.size)) % 4
+    return out
+
+
+def codes_to_seq(codes):
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
+
+
+def build_species_batch(O, rng, n_docs, genome_len, divergence=(0.0005, 0.01), k=31, fpr=0.3, size_spread=0.3):
+    """A phylogenetic batch the way COBS builds one (classic index, one hash, canonical k-mers):
+    an ancestral genome, `n_docs` strains derived from it through a random tree of substitutions
+    (so documents are strongly correlated) and of varying length, signature_size = max k-mers /
+    -ln(1 - fpr) (= 2.80 x for the 661k indexes' fpr 0.3).  Every canonical k-mer
+    of a strain sets its bit.  Returns (index bytes, list of strain code arrays, names)."""
+    anc = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+    strains = [anc]
+    while len(strains) < n_docs + 1:                         # random tree: each new strain mutates an earlier one
+        parent = strains[int(rng.integers(0, len(strains)))]
+        strains.append(mutate(rng, parent, float(rng.uniform(*divergence))))
+    strains = strains[1:]
+    strains = [s[: int(genome_len * (1.0 - size_spread * rng.random()))] for s in strains]
+    max_kmers = max(len(s) for s in strains) - k + 1
+    S = int(np.ceil(max_kmers / -np.log(1.0 - fpr)))
+    rb = (n_docs + 7) // 8
+    matrix = np.zeros((S, rb), dtype=np.uint8)
+    for d, s in enumerate(strains):
+        hs = O.create_hashes(codes_to_seq(s), k, 1, 1)
+        rows = np.unique((hs % np.uint64(S)).astype(np.int64))
+        matrix[rows, d >> 3] |= np.uint8(1 << (d & 7))
+    names = doc_names(rng, n_docs)
+    return O.make_index(k, 1, S, 1, names, matrix), strains, names
+
+
+def sample_reads(rng, strains, n_reads, read_len=150, error=0.01):
+    """reads from random strains with substitution errors: list of (strain index, sequence str)"""
+    out = []
+    for _ in range(n_reads):
+        d = int(rng.integers(0, len(strains)))
+        s = strains[d]
+        p = int(rng.integers(0, len(s) - read_len))
+        out.append((d, codes_to_seq(mutate(rng, s[p:p + read_len], error)).decode()))
+    return out

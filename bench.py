@@ -464,6 +464,10 @@ def main():
                               if head == "fetch_all_rows" else
                               ": a signature line is no longer fetched once none of its documents can reach "
                               "ceil(threshold*k-mers); identical results, data-dependent speed")),
+        "value_note": ("round 1 reported the threshold_bound mode as `value` (5.3e8 k-mers/s, roofline priced at bytes it "
+                       "did not move); since round 2 `value`/`roofline` are the fetch-every-row scan and the product "
+                       "default is the `threshold_bound` object -- compare that one with round 1"
+                       if head == "fetch_all_rows" else "headline switched to the data-dependent threshold_bound mode by --headline"),
         "hbm_fraction_whole_step": sum_head["hbm_fraction_whole_step_algorithmic"],
         "hits": sum_head["hits"],
         "planted_pairs_at_or_above_threshold": sure_hits,

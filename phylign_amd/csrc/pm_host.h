@@ -1,0 +1,145 @@
+// pm_host.h -- shared by the host translation units of libphylign_match.so
+// (pm_runtime.cpp, pm_index.cpp, pm_queries.cpp, pm_search.cpp, pm_text.cpp).
+// Not part of the C ABI (that is include/phylign_match.h).
+//
+// The reference reaches this functionality through `cobs query ...`
+// (scripts/run_cobs_streaming.sh:24-29; Snakefile:419-424, :476-481) and
+// `postprocess_cobs.py -n N` (scripts/postprocess_cobs.py:21-39).
+// No CPU fallback exists anywhere in these files: scoring happens only in pm_kernels.hip.
+#pragma once
+#include "../../include/phylign_match.h"
+#include "pm_internal.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <unistd.h>
+#include <vector>
+
+using namespace pm;
+
+// ------------------------------------------------------------------ errors
+// sets the calling thread's pm_last_error() text, returns `code`
+int fail(int code, const char* fmt, ...);
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);             \
+    } while (0)
+
+struct HitBuf { uint4* p; uint64_t cap; };
+struct PinBuf { void* p; size_t bytes; };
+// Per-search scratch that must stay untouched while the search is in flight (several
+// searches may be queued back to back: pm_search_async): record counters with their pinned
+// mirror, batch descriptors, timing events.  Pooled in the context, grow-only.
+struct Workspace {
+    unsigned long long* d_cnt = nullptr;      // [0] records written, [1] runs
+    unsigned long long* h_cnt = nullptr;      // pinned, device-mapped mirror: written by k_publish behind the scans
+    unsigned long long* h_cnt_dev = nullptr;  // its device address
+    // batch descriptors: 5 slices of desc_cap entries (base + one per query counter-width class, which
+    // carries the block ranges of a mixed-width launch); `uploaded` is what the device copy holds, so
+    // a step loop over the same indexes uploads nothing (and puts no DMA on the compute stream)
+    BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr; size_t desc_cap = 0;
+    std::vector<BatchDesc> uploaded;
+    std::vector<hipEvent_t> events;
+    hipEvent_t done = nullptr;                // recorded behind the counter read-back
+    bool busy = false;
+};
+constexpr uint32_t kFetchShards = 4096;       // counters of the "count_fetched" measurement option
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;             // hash + scan kernels
+    hipStream_t copy_stream = nullptr;        // index upload (H2D + re-stride)
+    hipStream_t d2h_stream = nullptr;         // hit records to the host: never queues behind later kernels
+    std::vector<Workspace*> ws;
+    std::vector<HitBuf> free_hits;
+    std::vector<PinBuf> free_pinned;
+    unsigned long long* d_fetch = nullptr;
+    uint64_t hit_hint = 0;                    // most records one search produced so far: sizes the next hit buffer
+};
+extern Ctx g_ctx;
+// HIP's current device is a per-thread setting that starts at 0: every entry point
+// that allocates, copies or launches binds the CALLING thread to the library's
+// device first, so loader threads of a rank with local_rank != 0 never end up
+// on GPU 0 (phylign_amd/match_stage.py loads indexes from a thread pool).
+int bind_thread();
+#define NEED_DEV()                                  \
+    do {                                            \
+        int rc_dev_ = bind_thread();                \
+        if (rc_dev_) return rc_dev_;                \
+    } while (0)
+// frees from any thread: the owning device must be current for the runtime's bookkeeping
+static inline void bind_thread_quiet() { if (g_ctx.ready) (void)hipSetDevice(g_ctx.device); }
+
+// ------------------------------------------------------------------ objects
+struct pm_index {
+    pm_index_info_t info{};
+    std::string names_blob;            // all names, '\0' separated
+    std::vector<uint64_t> name_off;    // n_docs + 1
+    uint8_t* d_matrix = nullptr;
+    int g = 1;                         // lanes per row
+    uint32_t slabs = 1;
+    // compact index: one sub-index per page column, each a matrix of its own
+    // (signature_size_p, num_hashes_p) that is page_size bytes wide; empty for classic
+    std::vector<pm_index*> parts;
+    uint64_t page_size = 0;
+    // every document name holds a '_' (the "<random prefix>_<accession>" shape the reference's
+    // post-filter relies on, scripts/postprocess_cobs.py:16-18); false -> the n-best cut is
+    // never taken on the GPU for this index (see enqueue_search)
+    bool names_have_sep = true;
+};
+
+struct pm_queries {
+    uint32_t k = 0;
+    std::vector<std::string> headers;       // header line without its first byte
+    std::vector<uint8_t> headerless;        // 1: sequence lines came before any header ("\tN" is printed without '*')
+    std::string seqs;                       // packed sequences (host copy, for the 04_filter emit)
+    std::vector<uint64_t> seq_off;          // n_queries + 1
+    std::vector<uint32_t> n_terms;
+    uint64_t total_terms = 0;
+    uint64_t n_slots = 0;                   // padded to 8 per query
+    std::vector<QDesc> qd;
+    // plane classes: queries ordered by class, ranges per class
+    std::vector<uint32_t> qmap;
+    std::vector<uint32_t> blkq;             // 8-slot block -> query
+    bool on_device = false;
+    uint32_t class_begin[5] = {0, 0, 0, 0, 0};
+    // device
+    uint8_t* d_seq = nullptr;
+    QDesc* d_qd = nullptr;
+    uint32_t* d_blkq = nullptr;
+    uint32_t* d_qmap = nullptr;
+    uint32_t* d_thr = nullptr; double thr_for = -1.0;      // per-query minimum score, cached per threshold
+    // hash buffers per (canonicalize, num_hashes); the kernel re-runs once per pm_search
+    struct HashBuf { int canon; uint32_t nh; uint64_t* d; uint64_t epoch; };
+    std::vector<HashBuf> hashes;
+    uint64_t epoch = 0;
+};
+
+// pm_queries.cpp: HBM copies of a query set on first use; device hashes per (canonicalize, num_hashes)
+int upload_queries(pm_queries* q);
+int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out);
+static const int kPlaneClass[4] = {7, 10, 16, 24};
+// pm_set_option("threshold_bound"): product default on; off reproduces the fetch-everything scan
+extern uint32_t g_threshold_bound;
+// pm_set_option("count_fetched"): the scan also counts the algorithmic bytes it really gathered
+extern uint32_t g_count_fetched;
+// pm_set_option("single_launch"): every row width (up to 1024 B) goes into the mixed-width launch
+extern uint32_t g_single_launch;
+
+// pm_search.cpp: cobs' line order on records: (slot, query, count records first, score desc, doc asc)
+bool hit_less(const pm_hit_t& a, const pm_hit_t& b);
+void order_hits(pm_hit_t* h, uint64_t n);

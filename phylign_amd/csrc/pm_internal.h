@@ -1,4 +1,4 @@
-// pm_internal.h -- shared between pm_host.cpp (host orchestration) and
+// pm_internal.h -- shared between the host translation units (pm_*.cpp, see pm_host.h) and
 // pm_kernels.hip (gfx950 kernels).  Not part of the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>

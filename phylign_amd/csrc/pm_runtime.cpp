@@ -1,0 +1,102 @@
+// pm_runtime.cpp -- process-wide state of libphylign_match.so: error text, the GPU binding
+// (pm_init / per-thread hipSetDevice), streams, option switches, pm_threshold_terms.
+#include "pm_host.h"
+
+static thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+Ctx g_ctx;
+int bind_thread() {
+    if (!g_ctx.ready) return fail(PM_ENODEV, "pm_init() has not succeeded: no GPU bound (there is no CPU fallback)");
+    hipError_t e = hipSetDevice(g_ctx.device);
+    if (e != hipSuccess) return fail(PM_EHIP, "hipSetDevice(%d): %s", g_ctx.device, hipGetErrorString(e));
+    return PM_OK;
+}
+uint32_t g_threshold_bound = 1;
+uint32_t g_count_fetched = 0;
+uint32_t g_single_launch = 0;
+
+// ------------------------------------------------------------------ runtime
+extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pm_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PM_ENODEV, "no HIP device visible (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(PM_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PM_ENODEV, "device %d is %s; this build targets gfx950 only", device, prop.gcnArchName);
+    if (g_ctx.ready && g_ctx.device == device) return PM_OK;
+    if (g_ctx.ready) pm_shutdown();
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.d2h_stream, hipStreamNonBlocking));
+    g_ctx.device = device;
+    g_ctx.ready = true;
+    return PM_OK;
+}
+
+extern "C" void pm_shutdown(void) {
+    if (!g_ctx.ready) return;
+    bind_thread_quiet();
+    hipDeviceSynchronize();
+    hipStreamDestroy(g_ctx.stream);
+    hipStreamDestroy(g_ctx.copy_stream);
+    hipStreamDestroy(g_ctx.d2h_stream);
+    for (Workspace* w : g_ctx.ws) {
+        if (w->d_cnt) hipFree(w->d_cnt);
+        if (w->h_cnt) hipHostFree(w->h_cnt);
+        if (w->d_desc) hipFree(w->d_desc);
+        if (w->h_desc) hipHostFree(w->h_desc);
+        for (auto e : w->events) hipEventDestroy(e);
+        if (w->done) hipEventDestroy(w->done);
+        delete w;
+    }
+    for (auto& b : g_ctx.free_hits) hipFree(b.p);
+    if (g_ctx.d_fetch) hipFree(g_ctx.d_fetch);
+    for (auto& b : g_ctx.free_pinned) hipHostFree(b.p);
+    g_ctx = Ctx();
+}
+
+extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus) {
+    NEED_DEV();
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g_ctx.device));
+    if (name && cap) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    if (hbm_total) *hbm_total = tot;
+    if (hbm_free) *hbm_free = fr;
+    if (n_cus) *n_cus = prop.multiProcessorCount;
+    return PM_OK;
+}
+
+extern "C" void pm_free(void* p) { free(p); }
+
+extern "C" int pm_set_option(const char* name, int64_t value) {
+    if (!name) return fail(PM_EINVAL, "bad argument");
+    if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
+    if (strcmp(name, "count_fetched") == 0) { g_count_fetched = value ? 1u : 0u; return PM_OK; }
+    if (strcmp(name, "single_launch") == 0) { g_single_launch = value ? 1u : 0u; return PM_OK; }
+    return fail(PM_EINVAL, "unknown option '%s'", name);
+}
+
+// The ONE place that turns `-t` into a minimum score (cobs counts_to_result):
+// ceil(threshold * num_terms) in IEEE double.  config.yaml:20 -> Snakefile:410.
+extern "C" uint32_t pm_threshold_terms(double threshold, uint64_t num_terms) {
+    double t = std::ceil(threshold * (double)num_terms);
+    if (!(t > 0)) return 0;
+    if (t > 4294967295.0) return 4294967295u;
+    return (uint32_t)t;
+}
+

@@ -1,0 +1,288 @@
+// pm_text.cpp -- cobs result text (a7), the fused post-filter (a8) and the native
+// 04_filter merge: host work, no GPU needed.
+#include "pm_host.h"
+
+// --------------------------------------------------------------------- text
+// cobs stdout grammar (witnesses: scripts/postprocess_cobs.py:23-26, :10-13;
+// scripts/filter_queries.py:51-65): "*<header>\t<N>\n" then N lines
+// "<doc name>\t<score>\n", best score first, ties by document index.
+// nb_best_hits >= 0 fuses scripts/postprocess_cobs.py:16-39: header untouched,
+// each name cut to "_" + what follows its first '_', the first n lines kept plus
+// later lines whose score equals the n-th score.
+static inline void append_tab_uint_nl(std::string& out, uint64_t v) {     // "\t<v>\n"
+    char buf[24]; int n = 0;
+    do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    out.push_back('\t');
+    while (n) out.push_back(buf[--n]);
+    out.push_back('\n');
+}
+
+// formats the records of queries [qa, qb) (a slice of one slot's ordered records) into `out`;
+// returns PM_OK or an error code with the message in `err`
+static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_hit_t* mine, size_t n_mine,
+                              size_t qa, size_t qb, int64_t nb_best, std::string& out, std::string& err) {
+    char msg[512];
+    size_t p = (size_t)(std::lower_bound(mine, mine + n_mine, (uint32_t)qa,
+                                         [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
+    for (size_t qi = qa; qi < qb; ++qi) {
+        size_t e = p;
+        while (e < n_mine && mine[e].query == qi) ++e;
+        size_t total = e - p;
+        if (p < e && mine[p].doc == PM_DOC_COUNT) {
+            // count records lead the run: cut on the GPU (one record: the number of documents that
+            // passed -t) or raw device runs of several column slabs / sub-indexes (they add up)
+            total = 0;
+            while (p < e && mine[p].doc == PM_DOC_COUNT) { total += mine[p].score; ++p; }
+        }
+        if (!q->headerless[qi]) out.push_back('*');
+        else if (nb_best >= 0) {    // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
+            snprintf(msg, sizeof msg, "record %zu has sequence lines before any FASTA header: the post-filter cannot parse its result", qi);
+            err = msg;
+            return PM_EINVAL;
+        }
+        out += q->headers[qi];
+        append_tab_uint_nl(out, total);
+        uint32_t min_kmers = 0;
+        for (size_t i = p; i < e; ++i) {
+            if (mine[i].doc >= ix->info.n_docs) {
+                snprintf(msg, sizeof msg, "hit record (query %u, doc %u) out of range for this index", mine[i].query, mine[i].doc);
+                err = msg;
+                return PM_EINVAL;
+            }
+            const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
+            const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
+            if (nb_best < 0) {
+                out.append(nm, nl);
+                append_tab_uint_nl(out, mine[i].score);
+                continue;
+            }
+            const int64_t rank = (int64_t)(i - p) + 1;      // 1-based like the post-filter's counter
+            const char* us = (const char*)memchr(nm, '_', nl);
+            if (!us) {
+                // postprocess_cobs.py:16-18 turns such a line into a bare "_" (no newline) and
+                // raises on int("_") once rank >= n: an error for the whole rule
+                if (rank < nb_best) { out.push_back('_'); continue; }
+                snprintf(msg, sizeof msg, "document name '%.*s' has no '_' separator (post-filter cannot parse it)", (int)nl, nm);
+                err = msg;
+                return PM_EINVAL;
+            }
+            bool keep;
+            if (rank < nb_best) keep = true;
+            else if (rank == nb_best) { keep = true; min_kmers = mine[i].score; }
+            else keep = mine[i].score == min_kmers;
+            if (keep) {
+                out.append(us, nl - (size_t)(us - nm));
+                append_tab_uint_nl(out, mine[i].score);
+            }
+        }
+        p = e;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
+                              const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                              int64_t nb_best, char** text, size_t* len) {
+    if (!ix || !q || (!hits && n_hits) || !text || !len) return fail(PM_EINVAL, "bad argument");
+    const size_t nq = q->headers.size();
+    // records as pm_result_hits_* deliver them are already in line order: the slot's records are
+    // one contiguous slice; anything else (gathered, hand-made) is copied and ordered first
+    std::vector<pm_hit_t> copy;
+    const pm_hit_t* mine = hits;
+    size_t n_mine = 0;
+    if (std::is_sorted(hits, hits + n_hits, [](const pm_hit_t& a, const pm_hit_t& b) { return hit_less(a, b); })) {
+        const pm_hit_t* lo = std::lower_bound(hits, hits + n_hits, slot, [](const pm_hit_t& h, uint32_t v) { return h.slot < v; });
+        const pm_hit_t* hi = std::upper_bound(lo, hits + n_hits, slot, [](uint32_t v, const pm_hit_t& h) { return v < h.slot; });
+        mine = lo; n_mine = (size_t)(hi - lo);
+    } else {
+        for (uint64_t i = 0; i < n_hits; ++i) if (hits[i].slot == slot) copy.push_back(hits[i]);
+        order_hits(copy.data(), copy.size());
+        mine = copy.data(); n_mine = copy.size();
+    }
+    if (n_mine && mine[n_mine - 1].query >= nq)
+        return fail(PM_EINVAL, "hit record (query %u) out of range for this query set", mine[n_mine - 1].query);
+    // query ranges are independent: format them on several host threads (at 1 M queries a single
+    // thread spends seconds per batch here, scripts/postprocess_cobs.py far more)
+    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), (nq + n_mine / 8) / 4096);
+    if (nt < 1) nt = 1;
+    std::vector<std::string> parts(nt), errs(nt);
+    std::vector<int> rcs(nt, PM_OK);
+    // split by records + queries so that long hit lists spread evenly
+    std::vector<size_t> cutq(nt + 1, nq);
+    cutq[0] = 0;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t target = (n_mine + nq) * t / nt;          // position in the merged (records + headers) stream
+        size_t lo = cutq[t - 1], hi = nq;                        // smallest query whose prefix weight reaches target
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            const size_t recs = (size_t)(std::lower_bound(mine, mine + n_mine, (uint32_t)mid,
+                                                          [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
+            if (recs + mid < target) lo = mid + 1; else hi = mid;
+        }
+        cutq[t] = lo;
+    }
+    auto work = [&](size_t t) {
+        parts[t].reserve((size_t)((double)(n_mine * 28 + nq * 24) / (double)nt * 1.1) + 64);
+        rcs[t] = format_query_range(ix, q, mine, n_mine, cutq[t], cutq[t + 1], nb_best, parts[t], errs[t]);
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (size_t t = 0; t < nt; ++t)
+        if (rcs[t] != PM_OK) return fail(rcs[t], "%s", errs[t].c_str());      // the first failing query range, as a serial pass would report
+    size_t total = 0;
+    for (auto& s2 : parts) total += s2.size();
+    char* buf = (char*)malloc(total + 1);
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    size_t o = 0;
+    for (auto& s2 : parts) { memcpy(buf + o, s2.data(), s2.size()); o += s2.size(); }
+    buf[total] = 0;
+    *text = buf; *len = total;
+    return PM_OK;
+}
+
+extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len,
+                             double threshold, int64_t nb_best, char** text, size_t* len) {
+    NEED_DEV();
+    if (!ix) return fail(PM_EINVAL, "bad argument");
+    pm_queries_t* q = nullptr; pm_result_t* r = nullptr;
+    int rc = pm_queries_parse(fasta, fasta_len, ix->info.term_size, &q);
+    if (rc) return rc;
+    uint64_t nq = 0; pm_queries_count(q, &nq, nullptr);
+    const pm_hit_t* hits = nullptr; uint64_t n = 0;
+    if (nq) {
+        pm_index_t* arr[1] = {ix};
+        rc = pm_search(arr, 1, q, threshold, nb_best > 0 ? (uint32_t)std::min<int64_t>(nb_best, 0xFFFFFFFFll) : 0u, 0, &r);
+        if (rc == PM_OK) rc = pm_result_hits_host(r, &hits, &n);
+    }
+    if (rc == PM_OK) rc = pm_format_hits(ix, q, hits, n, 0, nb_best, text, len);
+    if (r) pm_result_free(r);
+    pm_queries_free(q);
+    return rc;
+}
+
+// --------------------------------------------------------- 04_filter merge
+// Native form of the reference's consumer (scripts/filter_queries.py:107-206):
+// for every query keep the globally best `keep` matches across batches plus the
+// ones tied with the last of them, ordered by (-kmers, batch, ref), and emit
+// ">qname ref1,ref2,...\nseq".  What is merged per batch is what the 03_match
+// file of that batch holds, i.e. the hit list after the per-batch post-filter
+// (scripts/postprocess_cobs.py:21-39 with -n nb_best_hits).
+struct MergeItem { uint32_t kmers; uint32_t batch; std::string ref; };
+struct pm_merge {
+    const pm_queries* q = nullptr;
+    uint32_t keep = 0;
+    std::vector<std::string> batches;
+    std::map<std::string, uint32_t> by_name;        // query name (first word) -> record index
+    std::vector<std::string> qnames;
+    std::vector<std::vector<MergeItem>> items;
+    std::vector<uint32_t> floor_;
+};
+
+extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
+    if (!q || !out) return fail(PM_EINVAL, "bad argument");
+    pm_merge* m = new pm_merge();
+    m->q = q; m->keep = keep;
+    const size_t nq = q->headers.size();
+    m->items.resize(nq); m->floor_.assign(nq, 0); m->qnames.resize(nq);
+    for (size_t i = 0; i < nq; ++i) {
+        // readfq name: the header up to its first space (scripts/filter_queries.py:80)
+        const std::string& h = q->headers[i];
+        m->qnames[i] = h.substr(0, h.find(' '));
+        m->by_name[m->qnames[i]] = (uint32_t)i;        // duplicates: the last record wins, as in a dict
+    }
+    *out = m;
+    return PM_OK;
+}
+
+extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* ix,
+                            const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
+    if (!m || !batch || !ix || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
+    const size_t nq = m->q->headers.size();
+    std::vector<pm_hit_t> mine;
+    for (uint64_t i = 0; i < n_hits; ++i)
+        if (hits[i].slot == slot && hits[i].doc != PM_DOC_COUNT) {
+            if (hits[i].query >= nq || hits[i].doc >= ix->info.n_docs)
+                return fail(PM_EINVAL, "hit record out of range for batch %s", batch);
+            mine.push_back(hits[i]);
+        }
+    order_hits(mine.data(), mine.size());
+    const uint32_t bid = (uint32_t)m->batches.size();
+    m->batches.push_back(batch);
+    size_t p = 0;
+    while (p < mine.size()) {
+        size_t e = p;
+        const uint32_t qi = mine[p].query;
+        while (e < mine.size() && mine[e].query == qi) ++e;
+        // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
+        // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
+        const std::string& h = m->q->headers[qi];
+        std::string key = h.substr(0, h.find('\t'));
+        key = key.substr(0, key.find(' '));
+        auto it = m->by_name.find(key);
+        if (it == m->by_name.end()) return fail(PM_EINVAL, "query '%s' of batch %s is not in the query file", key.c_str(), batch);
+        const uint32_t target = it->second;
+        std::vector<MergeItem>& v = m->items[target];
+        uint32_t nth = 0;
+        for (size_t i = p; i < e; ++i) {
+            if (nb_best >= 0) {                          // per-batch post-filter, same rule as pm_format_hits
+                const int64_t rank = (int64_t)(i - p) + 1;
+                if (rank == nb_best) nth = mine[i].score;
+                if (rank > nb_best && mine[i].score != nth) continue;
+            }
+            const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
+            const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
+            const char* us = (const char*)memchr(nm, '_', nl);
+            if (!us || memchr(us + 1, '_', nl - (size_t)(us + 1 - nm)))
+                return fail(PM_EINVAL, "document name '%.*s' must hold exactly one '_' (scripts/filter_queries.py:64)", (int)nl, nm);
+            if (mine[i].score >= m->floor_[target])
+                v.push_back({mine[i].score, bid, std::string(us + 1, nl - (size_t)(us + 1 - nm))});
+        }
+        std::sort(v.begin(), v.end(), [&](const MergeItem& a, const MergeItem& b) {
+            if (a.kmers != b.kmers) return a.kmers > b.kmers;
+            if (a.batch != b.batch) return m->batches[a.batch] < m->batches[b.batch];
+            return a.ref < b.ref;
+        });
+        if (v.size() > m->keep) {
+            if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
+            size_t cut = m->keep;
+            m->floor_[target] = v[cut - 1].kmers;
+            while (cut < v.size() && v[cut].kmers == m->floor_[target]) ++cut;
+            v.resize(cut);
+        }
+        p = e;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
+    if (!m || !text || !len) return fail(PM_EINVAL, "bad argument");
+    std::string out;
+    const pm_queries* q = m->q;
+    // dict semantics of the consumer: one record per distinct name, at the position of its
+    // first occurrence, with the sequence of its last occurrence
+    std::vector<char> seen(q->headers.size(), 0);
+    for (size_t i = 0; i < q->headers.size(); ++i) {
+        const uint32_t rec = m->by_name.at(m->qnames[i]);
+        if (seen[rec]) continue;
+        seen[rec] = 1;
+        out.push_back('>'); out += m->qnames[i]; out.push_back(' ');
+        const std::vector<MergeItem>& v = m->items[rec];
+        for (size_t k = 0; k < v.size(); ++k) { if (k) out.push_back(','); out += v[k].ref; }
+        out.push_back('\n');
+        out.append(q->seqs, (size_t)q->seq_off[rec], (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]));
+        out.push_back('\n');
+    }
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
+    *text = buf; *len = out.size();
+    return PM_OK;
+}
+
+extern "C" void pm_merge_free(pm_merge_t* m) { delete m; }
+

@@ -237,8 +237,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef PM_SCAN_MIN_WAVES
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
+// register budget of the wide counter classes (queries of 1 024 ... 2^24 k-mers hold 64 / 96 plane
+// registers): measured on 9.7 kbp / 100 kbp queries, see DESIGN.md section 6
+#ifndef PM_SCAN_WAVES_P16
+#define PM_SCAN_WAVES_P16 4
+#endif
+#ifndef PM_SCAN_WAVES_P24
+#define PM_SCAN_WAVES_P24 2
+#endif
 template <int G, int P, bool NH1>
-__global__ __launch_bounds__(256, PM_SCAN_MIN_WAVES) void k_scan(const ScanArgs a)
+__global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_SCAN_WAVES_P16 : PM_SCAN_WAVES_P24))) void k_scan(const ScanArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

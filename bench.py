@@ -182,6 +182,8 @@ def main():
     pm.init(local_rank)
     if os.environ.get("PM_SINGLE_LAUNCH"):
         pm.set_option("single_launch", 1)
+    if os.environ.get("PM_WIDE_QUERY"):
+        pm.set_option("wide_query", int(os.environ["PM_WIDE_QUERY"]))
     dev = pm.device_info()
     log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
 

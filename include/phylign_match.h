@@ -102,6 +102,8 @@ typedef struct {
     uint64_t algorithmic_bytes;  /* sum over its batches and k-mers of num_hashes * row_bytes */
     double   ms;                 /* hipEvent duration on the launch stream */
     uint64_t fetched_bytes;      /* option "count_fetched": the part of algorithmic_bytes really gathered */
+    uint32_t wide_query;         /* 1: several lane groups of a workgroup shared each query (few, long queries) */
+    uint32_t reserved;
 } pm_launch_t;
 
 /* ---- runtime ---------------------------------------------------------- */
@@ -115,7 +117,11 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * score any more (count so far + k-mers left < minimum); hits and scores are
  * identical either way, 0 makes the scan fetch every row like cobs does.
  * "count_fetched" (default 0): the scan also counts the algorithmic bytes of the
- * row chunks it really gathered (pm_stats_t / pm_launch_t .fetched_bytes). */
+ * row chunks it really gathered (pm_stats_t / pm_launch_t .fetched_bytes).
+ * "wide_query" (default 0 = automatic): query classes of 128+ k-mers with too few queries
+ * to fill the GPU are scanned with several lane groups per query (partial counts added
+ * through LDS; the threshold bound is off in that form); 1 = always, 2 = never.
+ * "single_launch" (default 0): rows of every width up to 1024 B share one launch. */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);

@@ -43,7 +43,7 @@ class Stats(C.Structure):
 class Launch(C.Structure):
     _fields_ = [("lanes_per_row", C.c_uint32), ("planes", C.c_uint32), ("num_hashes", C.c_uint32),
                 ("n_batches", C.c_uint32), ("n_queries", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
-                ("ms", C.c_double), ("fetched_bytes", C.c_uint64)]
+                ("ms", C.c_double), ("fetched_bytes", C.c_uint64), ("wide_query", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("doc", "<u4"), ("score", "<u4"), ("slot", "<u4")])
@@ -322,7 +322,7 @@ class Result:
         _chk(load().pm_result_launches(self._h, None, 0, C.byref(n)))
         arr = (Launch * max(n.value, 1))()
         _chk(load().pm_result_launches(self._h, arr, n.value, C.byref(n)))
-        return [{"kernel": f"k_scan<G={a.lanes_per_row or 'mixed'},P={a.planes},{'NH1' if a.num_hashes == 1 else 'NHn'}>",
+        return [{"kernel": f"k_scan<G={a.lanes_per_row or 'mixed'},P={a.planes},{'NH1' if a.num_hashes == 1 else 'NHn'}{',WQ' if a.wide_query else ''}>",
                  "n_batches": a.n_batches, "n_queries": a.n_queries,
                  "algorithmic_bytes": a.algorithmic_bytes, "ms": a.ms,
                  "fetched_bytes": a.fetched_bytes} for a in arr[: n.value]]

@@ -139,6 +139,9 @@ extern uint32_t g_threshold_bound;
 extern uint32_t g_count_fetched;
 // pm_set_option("single_launch"): every row width (up to 1024 B) goes into the mixed-width launch
 extern uint32_t g_single_launch;
+// pm_set_option("wide_query"): 0 = automatic (few long queries: several lane groups share a query), 1 = always
+// where instantiated (128+ k-mers per query), 2 = never
+extern uint32_t g_wide_query;
 
 // pm_search.cpp: cobs' line order on records: (slot, query, count records first, score desc, doc asc)
 bool hit_less(const pm_hit_t& a, const pm_hit_t& b);

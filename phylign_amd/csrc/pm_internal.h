@@ -51,6 +51,8 @@ struct ScanArgs {
     uint32_t        pad_;
     uint4*          runs;       // run directory {query, slot, first record, hits | cut flag << 31}
     uint64_t        run_cap;
+    uint32_t        wide_query; // 1: several lane groups of a workgroup share one query (k_scan<..., WQ>)
+    uint32_t        pad2_;
 };
 
 // launchers (pm_kernels.hip); all asynchronous on `st`, return hipError_t
@@ -61,7 +63,7 @@ hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t
 // planes = counter bit planes (7,10,16,24);
 // slabs > 1 only with n_batches == 1 (rows wider than 1024 B)
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st);
-uint32_t scan_queries_per_block(int g);
+uint32_t scan_queries_per_block(int g, bool wide_query);
 uint64_t barrett_m(uint64_t S);
 hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst, uint64_t stride,
                            uint64_t n_rows, hipStream_t st);

@@ -242,11 +242,21 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef PM_SCAN_WAVES_P16
 #define PM_SCAN_WAVES_P16 4
 #endif
+#ifndef PM_SCAN_WAVES_P16_WQ
+#define PM_SCAN_WAVES_P16_WQ 3       // the wide-query form needs a few registers more: 92 B of scratch at 4 waves
+#endif
 #ifndef PM_SCAN_WAVES_P24
 #define PM_SCAN_WAVES_P24 2
 #endif
-template <int G, int P, bool NH1>
-__global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_SCAN_WAVES_P16 : PM_SCAN_WAVES_P24))) void k_scan(const ScanArgs a)
+// WQ ("wide query") instantiations: a query set of few, long queries leaves most of the chip idle when
+// one lane group walks a whole query (a 100 kbp plasmid = 12 500 serial steps).  Here NGRP =
+// min(8, 256 / G) lane groups of ONE workgroup share a query: group `sub` takes the steps sub,
+// sub + NGRP, ..., every group keeps partial bit-sliced counts, and after the loop they are added
+// pairwise through LDS (a ripple-carry adder over the P planes per tree level).  The threshold bound
+// is off in this form (partial counts say nothing about a document's total); group 0 of the
+// query runs the usual epilogue on the combined planes.  Results are identical to the plain form.
+template <int G, int P, bool NH1, bool WQ>
+__global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : PM_SCAN_WAVES_P24))) void k_scan(const ScanArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -266,7 +276,11 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_S
     const BatchDesc bd = a.batches[batch];            // uniform: scalar loads
     const uint32_t g = G > 0 ? (uint32_t)G : bd.lanes;               // power of two, 1..64
     const uint32_t gl = G > 0 ? (uint32_t)__builtin_ctz((unsigned)(G > 0 ? G : 1)) : (uint32_t)__builtin_ctz(bd.lanes);
-    const uint32_t li = (tile * 4u + (uint32_t)wave) * (64u >> gl) + ((uint32_t)lane >> gl);
+    const uint32_t gpb = 256u >> gl;                                  // lane groups per workgroup
+    const uint32_t gi = ((uint32_t)wave * 64u + (uint32_t)lane) >> gl; // my group inside the workgroup
+    const uint32_t ngrp = WQ ? (gpb < 8u ? gpb : 8u) : 1u;            // groups that share one query
+    const uint32_t sub = WQ ? (gi & (ngrp - 1u)) : 0u;
+    const uint32_t li = WQ ? (tile * gpb + gi) / ngrp : tile * gpb + gi;
     const uint32_t c = (uint32_t)lane & (g - 1u);
     const uint32_t slab = blockIdx.y;
     const uint64_t boff = ((uint64_t)slab * g + c) * 16;   // byte offset of this lane's chunk
@@ -303,9 +317,11 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_S
     uint32_t nfetch = 0;                              // 16-byte row chunks this lane gathered (measurement option)
     constexpr int TS = PM_SCAN_TERMS;                 // k-mers per step: 8 (or 4): loads in flight per lane
     constexpr uint32_t SPB = 8 / TS;                  // steps per 8-slot hash block
-    for (uint32_t sidx = 0; sidx < wmax * SPB; ++sidx) {
+    const uint32_t trips = WQ ? (wmax * SPB + ngrp - 1u) / ngrp : wmax * SPB;
+    for (uint32_t it = 0; it < trips; ++it) {
+        const uint32_t sidx = WQ ? it * ngrp + sub : it;          // my step of the query
         const uint32_t b = sidx / SPB, t0i = sidx * TS;           // block, first k-mer of this step
-        if (a.bound) {
+        if (!WQ && a.bound) {
             const int need = (int)thr - (int)(nt - t0i);          // score required now to still reach thr
             bool alive = line_alive;
             if (__any(alive && need > 0)) {
@@ -373,6 +389,39 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_S
         }
     }
 
+    if constexpr (WQ) {
+        // partial counts of the ngrp groups of a query -> its group 0, pairwise through LDS,
+        // PCH planes at a time (16 KB of LDS per workgroup whatever P is; the carry stays in registers)
+        constexpr int PCH = 4;
+        __shared__ u32x4 xch[PCH * 256];
+        const uint32_t tid = threadIdx.x;
+        for (uint32_t r = 1; r < ngrp; r <<= 1) {
+            const uint32_t m = 2u * r - 1u;
+            const bool writer = (sub & m) == r, reader = (sub & m) == 0u && sub + r < ngrp;
+            u32x4 carry = (u32x4)(0u);
+#pragma unroll
+            for (int p0 = 0; p0 < P; p0 += PCH) {
+                if (writer) {
+#pragma unroll
+                    for (int p = p0; p < p0 + PCH && p < P; ++p) xch[(p - p0) * 256 + tid] = pl[p];
+                }
+                __syncthreads();
+                if (reader) {
+#pragma unroll
+                    for (int p = p0; p < p0 + PCH && p < P; ++p) {
+                        const u32x4 o = xch[(p - p0) * 256 + tid + r * g];
+                        const u32x4 u = pl[p] ^ o;
+                        const u32x4 sum = u ^ carry;
+                        carry = (u & carry) | (pl[p] & o);
+                        pl[p] = sum;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const bool owner = !WQ || sub == 0u;              // the group that holds the query's total counts
+
     // ---- a7: score >= thr, bit-sliced: carry-out of score + (2^P - thr).
     // valid-document mask first (row padding, inactive lanes)
     const uint64_t doc0 = ((uint64_t)slab * g + c) * 128;
@@ -382,7 +431,7 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_S
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t first = doc0 + 32u * w;
-            if (!active || first >= bd.n_docs) kw[w] = 0u;
+            if (!active || !owner || first >= bd.n_docs) kw[w] = 0u;
             else if (first + 32 > bd.n_docs) kw[w] = (1u << (bd.n_docs - first)) - 1u;
             else kw[w] = 0xFFFFFFFFu;
         }
@@ -536,8 +585,16 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? PM_S
 template <int G, int P>
 static hipError_t scan_dispatch_nh(const ScanArgs& a, uint32_t slabs, hipStream_t st) {
     dim3 grid(G > 0 ? a.n_batches * a.tiles : a.total_blocks, slabs, 1);
-    if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true>), grid, dim3(256), 0, st, a);
-    else           hipLaunchKernelGGL((k_scan<G, P, false>), grid, dim3(256), 0, st, a);
+    if constexpr (P >= 10) {
+        if (a.wide_query) {
+            if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true, true>), grid, dim3(256), 0, st, a);
+            else           hipLaunchKernelGGL((k_scan<G, P, false, true>), grid, dim3(256), 0, st, a);
+            return hipGetLastError();
+        }
+    }
+    if (a.wide_query) return hipErrorInvalidValue;
+    if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true, false>), grid, dim3(256), 0, st, a);
+    else           hipLaunchKernelGGL((k_scan<G, P, false, false>), grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }
 template <int G>
@@ -550,7 +607,11 @@ static hipError_t scan_dispatch_p(const ScanArgs& a, int planes, uint32_t slabs,
         default: return hipErrorInvalidValue;
     }
 }
-uint32_t scan_queries_per_block(int g) { return 4u * (64u / (uint32_t)g); }
+// queries one workgroup takes: 256 / g lane groups, one query each, or (wide-query form) min(8, 256 / g) groups per query
+uint32_t scan_queries_per_block(int g, bool wide_query) {
+    const uint32_t gpb = 256u / (uint32_t)g;
+    return wide_query ? gpb / (gpb < 8u ? gpb : 8u) : gpb;
+}
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st) {
     if (a.nq == 0 || a.n_batches == 0) return hipSuccess;
     if (slabs > 1 && a.n_batches != 1) return hipErrorInvalidValue;

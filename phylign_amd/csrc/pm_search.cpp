@@ -231,6 +231,26 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
                 d.lanes = (uint32_t)ix->g; d.block_begin = 0; d.pad_ = 0;
             }
     }
+    // wide-query form per (group, query class): when one lane group per query would leave the chip
+    // mostly idle (few, long queries), min(8, 256 / lanes) groups share each query (k_scan<..., WQ>)
+    std::vector<uint8_t> use_wq(groups.size() * 4, 0);
+    for (size_t gi = 0; gi < groups.size(); ++gi)
+        for (int c = 1; c < 4; ++c) {                       // classes of 128+ k-mers per query
+            const uint32_t nqc = q->class_begin[c + 1] - q->class_begin[c];
+            if (nqc == 0 || g_wide_query == 2) continue;
+            uint64_t waves = 0;
+            for (size_t u : groups[gi].members) {
+                const uint32_t qpb = scan_queries_per_block(units[u].ix->g, false);
+                waves += 4ull * ((nqc + qpb - 1) / qpb) * units[u].ix->slabs;
+            }
+            // automatic: always when the plain form could not fill the chip (< 1.5 x the 4 096 wave slots of
+            // 4 waves/SIMD); narrow rows (one query per lane group of 1 ... 16 lanes) measure faster in this
+            // form at any query count, but only while every row is fetched anyway -- the form gives up the
+            // threshold bound (tools/variant_longq.sh)
+            const bool few = waves < 6144;
+            const bool narrow = groups[gi].g < 32;
+            use_wq[gi * 4 + (size_t)c] = (g_wide_query == 1 || few || (narrow && !g_threshold_bound)) ? 1 : 0;
+        }
     std::vector<uint32_t> mixed_blocks(groups.size() * 4, 0u);
     {
         size_t desc_off = 0;
@@ -244,7 +264,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
                     BatchDesc* stage = ws->h_desc + (size_t)(1 + c) * dcap + desc_off;
                     for (size_t k = 0; k < g.members.size(); ++k) {
                         stage[k] = ws->h_desc[desc_off + k];
-                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes);
+                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes, use_wq[gi * 4 + (size_t)c] != 0);
                         stage[k].block_begin = (uint32_t)blk;
                         blk += (e - b + qpb - 1) / qpb;
                     }
@@ -302,8 +322,9 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             ScanArgs a;
             a.batches = ws->d_desc + desc_off; a.n_batches = (uint32_t)g.members.size();
             a.tiles = 0; a.total_blocks = 0;
+            a.wide_query = use_wq[(size_t)(&g - groups.data()) * 4 + (size_t)c]; a.pad2_ = 0;
             if (g.g > 0) {
-                const uint32_t qpb = scan_queries_per_block(g.g);
+                const uint32_t qpb = scan_queries_per_block(g.g, a.wide_query != 0);
                 a.tiles = (e - b + qpb - 1) / qpb;
             } else {
                 // mixed widths: the slice of this query class holds the per-batch workgroup ranges
@@ -333,6 +354,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             for (uint32_t i = b; i < e; ++i) terms += q->n_terms[q->qmap[i]];
             pm_launch_t L{};
             L.lanes_per_row = (uint32_t)g.g; L.planes = (uint32_t)kPlaneClass[c]; L.num_hashes = g.nh;
+            L.wide_query = a.wide_query;
             L.n_batches = a.n_batches; L.n_queries = e - b;
             L.algorithmic_bytes = terms * g.nh * rowsum;
             r->launches.push_back(L);

@@ -258,3 +258,40 @@ def test_hit_buffer_overflow_reruns_with_the_exact_size(pm, oracle):
     b = pm.search_async([ix], q, 0.0, nb_best_hits=5)
     assert pm.format_hits(ix, q, b.hits(), nb_best_hits=5) == pm.query_text(ix, fasta, 0.0, nb_best_hits=5)
     assert pm.format_hits(ix, q, a.hits()) == exp
+
+
+@pytest.mark.parametrize("n_docs", [13, 100, 300, 664, 4000, 9001])
+def test_wide_query_form_is_bit_identical(pm, oracle, n_docs):
+    """few long queries: several lane groups of a workgroup share one query (partial counts added
+    through LDS).  Forced on (1), off (2) and automatic (0) give the same records, equal to the oracle."""
+    rng = np.random.default_rng(900 + n_docs)
+    lens = [150, 158, 200, 700, 1053, 1054, 1500, 4000, 9000] + ([70000] if n_docs in (100, 4000) else [])
+    queries = [(f"w{i}", rand_seq(rng, L)) for i, L in enumerate(lens)] + [(f"x{i}", rand_seq(rng, 1300)) for i in range(9)]
+    plant = []
+    for qi in range(len(queries)):
+        for j, fr in enumerate((1.0, 0.9, 0.75, 0.7, 0.69, 0.3)):
+            plant.append((qi, int(rng.integers(0, n_docs)), fr))
+    index, fasta, _ = build_case(oracle, rng, n_docs, 5000, queries, density=0.1, plant=plant)
+    ix = pm.Index.load_mem(index, layout=int(rng.integers(0, 3)))
+    other = pm.Index.synth(2, 200, 3000)                     # a second, narrow batch: the mixed-width launch
+    q = pm.Queries(fasta)
+    try:
+        got = {}
+        for mode in (2, 1, 0):
+            pm.set_option("wide_query", mode)
+            for thr in (0.7, 0.0):
+                for n in (0, 3):
+                    res = pm.search([ix, other], q, thr, nb_best_hits=n)
+                    got[(mode, thr, n)] = res.hits()
+                    if mode == 1:
+                        kinds = {L["kernel"] for L in res.launches()}
+                        assert any(",WQ>" in k for k in kinds) and any("P=7," in k and ",WQ" not in k for k in kinds), kinds
+        for thr in (0.7, 0.0):
+            for n in (0, 3):
+                assert np.array_equal(got[(1, thr, n)], got[(2, thr, n)]), (thr, n)
+                assert np.array_equal(got[(0, thr, n)], got[(2, thr, n)]), (thr, n)
+            assert pm.format_hits(ix, q, got[(1, thr, 0)], slot=0) == oracle.query_file(index, fasta, thr)
+    finally:
+        pm.set_option("wide_query", 0)
+    with pytest.raises(pm.PMError):
+        pm.set_option("wide_query", 3)

@@ -84,14 +84,19 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
     n = int(rng.choice([0, 1, 3, 100]))
     exp = [oracle.query_file(c[0], fasta, thr) for c in cases]
     got = {}
-    for bound in (1, 0):
-        pm.set_option("threshold_bound", bound)
-        r1 = pm.search_async(ixs, q, thr, slot_base=base, nb_best_hits=n)
-        r2 = pm.search_async(ixs, q, thr, slot_base=base)
-        got[bound] = (r1.hits(), r2.hits())
-    pm.set_option("threshold_bound", 1)
-    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
-    pruned, plain = got[1]
+    try:
+        for bound, wq in ((1, 0), (0, 0), (1, 1), (0, 2)):      # scan modes x wide-query form (auto, forced, off)
+            pm.set_option("threshold_bound", bound)
+            pm.set_option("wide_query", wq)
+            r1 = pm.search_async(ixs, q, thr, slot_base=base, nb_best_hits=n)
+            r2 = pm.search_async(ixs, q, thr, slot_base=base)
+            got[(bound, wq)] = (r1.hits(), r2.hits())
+    finally:
+        pm.set_option("threshold_bound", 1)
+        pm.set_option("wide_query", 0)
+    for key in got:
+        assert np.array_equal(got[key][0], got[(1, 0)][0]) and np.array_equal(got[key][1], got[(1, 0)][1]), key
+    pruned, plain = got[(1, 0)]
     for s, ix in enumerate(ixs):
         assert pm.format_hits(ix, q, plain, slot=base + s) == exp[s]
         if n:

@@ -62,14 +62,24 @@ class Admission:
 
     def __init__(self, budget):
         self.budget, self.resident, self.next_ticket = float(budget), 0.0, 0
+        self.aborted = False
         self.cv = threading.Condition()
 
     def acquire(self, ticket, need):
         with self.cv:
-            while ticket != self.next_ticket or (self.resident > 0 and self.resident + need > self.budget):
+            while not self.aborted and (ticket != self.next_ticket or
+                                        (self.resident > 0 and self.resident + need > self.budget)):
                 self.cv.wait()
+            if self.aborted:
+                raise RuntimeError("stage aborted")
             self.resident += need
             self.next_ticket += 1
+            self.cv.notify_all()
+
+    def abort(self):
+        """the consumer failed: nobody will return budget any more, waiting loaders must give up"""
+        with self.cv:
+            self.aborted = True
             self.cv.notify_all()
 
     def release(self, amount):
@@ -174,8 +184,8 @@ def main(argv=None):
 
     kept, names_of, log_rows, pending = [], {}, [], []
     nb = args.nb_best_hits
-    with ThreadPoolExecutor(max_workers=max(1, args.loaders)) as pool:
-        futures = [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
+
+    def consume(futures):
         for fut in futures:
             pos, ix, need, t_load = fut.result()
             b = batches[pos]
@@ -198,6 +208,16 @@ def main(argv=None):
             admit.release(need)
             log_rows.append({"batch": b, "load_s": round(t_load, 3), "gpu_ms": round(ms, 3), "hits": int(len(hits)),
                              "search_and_format_s": round(time.time() - t0, 3)})
+
+    with ThreadPoolExecutor(max_workers=max(1, args.loaders)) as pool:
+        futures = [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
+        try:
+            consume(futures)
+        except BaseException:
+            admit.abort()                    # loaders waiting for budget would wait forever otherwise
+            for f in futures:
+                f.cancel()
+            raise
     for p in pending:
         p.result()
     writers.shutdown()

@@ -168,6 +168,26 @@ def test_match_stage_end_to_end_single_rank(pm, oracle, tmp_path, n):
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, n)
 
 
+def test_match_stage_fails_fast_on_a_broken_index(pm, oracle, tmp_path):
+    """a truncated index stream in the middle of the batch list, loaders queued behind a tiny HBM
+    budget: the stage exits non-zero promptly (waiting loaders are told to give up) and leaves no
+    output for the broken batch and no .tmp file"""
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    broken = sorted(names)[2]
+    (tmp_path / "cobs" / f"{broken}.cobs_classic.xz").write_bytes(
+        lzma.compress(bytes(indexes[broken][: len(indexes[broken]) // 3]), preset=1))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+                        "--cobs-dir", str(tmp_path / "cobs"), "--sizes", str(tmp_path / "sizes.txt"),
+                        "--queries", str(tmp_path / "Q.fa"), "--out-dir", str(tmp_path / "03_match"),
+                        "--filter-out", str(tmp_path / "04_filter" / "Q.fa"), "--loaders", "3",
+                        "--max-resident-gb", "0.0000001"], capture_output=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert b"index stream ended" in r.stderr or b"xzcat failed" in r.stderr, r.stderr.decode()[-1500:]
+    assert not (tmp_path / "03_match" / f"{broken}____Q.gz").exists()
+    assert not list((tmp_path / "03_match").glob("*.tmp")) and not (tmp_path / "04_filter" / "Q.fa").exists()
+
+
 def test_match_stage_two_ranks_gather(pm, oracle, tmp_path):
     """the N>1 code path (static sharding, gather of hit records + names to rank 0) with two
     ranks sharing the one GPU over gloo; on a multi-GPU node the same code runs over RCCL"""

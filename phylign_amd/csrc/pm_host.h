@@ -28,6 +28,12 @@
 
 using namespace pm;
 
+// counter-width classes: queries of < 2^7, 2^10, 2^16, 2^20, 2^24 k-mers get bit-sliced per-document
+// counters of that many planes (one k_scan instantiation each), so short reads never pay for a
+// long gene or plasmid in the same FASTA
+constexpr int kNumClasses = 5;
+static const int kPlaneClass[kNumClasses] = {7, 10, 16, 20, 24};
+
 // ------------------------------------------------------------------ errors
 // sets the calling thread's pm_last_error() text, returns `code`
 int fail(int code, const char* fmt, ...);
@@ -116,7 +122,7 @@ struct pm_queries {
     std::vector<uint32_t> qmap;
     std::vector<uint32_t> blkq;             // 8-slot block -> query
     bool on_device = false;
-    uint32_t class_begin[5] = {0, 0, 0, 0, 0};
+    uint32_t class_begin[kNumClasses + 1] = {};
     // device
     uint8_t* d_seq = nullptr;
     QDesc* d_qd = nullptr;
@@ -132,7 +138,7 @@ struct pm_queries {
 // pm_queries.cpp: HBM copies of a query set on first use; device hashes per (canonicalize, num_hashes)
 int upload_queries(pm_queries* q);
 int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out);
-static const int kPlaneClass[4] = {7, 10, 16, 24};
+
 // pm_set_option("threshold_bound"): product default on; off reproduces the fetch-everything scan
 extern uint32_t g_threshold_bound;
 // pm_set_option("count_fetched"): the scan also counts the algorithmic bytes it really gathered

@@ -52,7 +52,7 @@ struct ScanArgs {
     uint4*          runs;       // run directory {query, slot, first record, hits | cut flag << 31}
     uint64_t        run_cap;
     uint32_t        wide_query; // 1: several lane groups of a workgroup share one query (k_scan<..., WQ>)
-    uint32_t        pad2_;
+    uint32_t        wq_groups;  // ... at most this many (power of two, 4 ... 256; capped by 256 / lanes per row)
 };
 
 // launchers (pm_kernels.hip); all asynchronous on `st`, return hipError_t
@@ -60,10 +60,10 @@ hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t
                              uint64_t n_slots, uint32_t k, int canon, uint32_t nh,
                              uint64_t* hashes, hipStream_t st);
 // g = lanes per row (1..64 pow2; 0 = mixed, taken per batch from BatchDesc.lanes),
-// planes = counter bit planes (7,10,16,24);
+// planes = counter bit planes (7,10,16,20,24);
 // slabs > 1 only with n_batches == 1 (rows wider than 1024 B)
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st);
-uint32_t scan_queries_per_block(int g, bool wide_query);
+uint32_t scan_queries_per_block(int g, uint32_t wq_groups);   // wq_groups = 0: plain form
 uint64_t barrett_m(uint64_t S);
 hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst, uint64_t stride,
                            uint64_t n_rows, hipStream_t st);

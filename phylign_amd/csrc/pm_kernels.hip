@@ -245,18 +245,22 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef PM_SCAN_WAVES_P16_WQ
 #define PM_SCAN_WAVES_P16_WQ 3       // the wide-query form needs a few registers more: 92 B of scratch at 4 waves
 #endif
+#ifndef PM_SCAN_WAVES_P20
+#define PM_SCAN_WAVES_P20 3
+#endif
 #ifndef PM_SCAN_WAVES_P24
 #define PM_SCAN_WAVES_P24 2
 #endif
 // WQ ("wide query") instantiations: a query set of few, long queries leaves most of the chip idle when
 // one lane group walks a whole query (a 100 kbp plasmid = 12 500 serial steps).  Here NGRP =
-// min(8, 256 / G) lane groups of ONE workgroup share a query: group `sub` takes the steps sub,
+// min(ScanArgs.wq_groups, 256 / G) lane groups of ONE workgroup share a query (wq_groups: a power of
+// two >= 4 chosen by the host, 8 unless narrow rows need more groups to fill the chip): group `sub` takes the steps sub,
 // sub + NGRP, ..., every group keeps partial bit-sliced counts, and after the loop they are added
 // pairwise through LDS (a ripple-carry adder over the P planes per tree level).  The threshold bound
 // is off in this form (partial counts say nothing about a document's total); group 0 of the
 // query runs the usual epilogue on the combined planes.  Results are identical to the plain form.
 template <int G, int P, bool NH1, bool WQ>
-__global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : PM_SCAN_WAVES_P24))) void k_scan(const ScanArgs a)
+__global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : (P <= 20 ? PM_SCAN_WAVES_P20 : PM_SCAN_WAVES_P24)))) void k_scan(const ScanArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
     const uint32_t gl = G > 0 ? (uint32_t)__builtin_ctz((unsigned)(G > 0 ? G : 1)) : (uint32_t)__builtin_ctz(bd.lanes);
     const uint32_t gpb = 256u >> gl;                                  // lane groups per workgroup
     const uint32_t gi = ((uint32_t)wave * 64u + (uint32_t)lane) >> gl; // my group inside the workgroup
-    const uint32_t ngrp = WQ ? (gpb < 8u ? gpb : 8u) : 1u;            // groups that share one query
+    const uint32_t ngrp = WQ ? (gpb < a.wq_groups ? gpb : a.wq_groups) : 1u;   // groups that share one query (power of two)
     const uint32_t sub = WQ ? (gi & (ngrp - 1u)) : 0u;
     const uint32_t li = WQ ? (tile * gpb + gi) / ngrp : tile * gpb + gi;
     const uint32_t c = (uint32_t)lane & (g - 1u);
@@ -380,8 +384,11 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
             carry = e0;
             first = 3;
         }
+        // wide-query form: a group counts at most a 1/ngrp share of the query's k-mers (+ 8) with
+        // ngrp >= 4, so its partial counts fit P - 1 planes; the top plane stays zero until the combine
+        constexpr int PL = WQ ? P - 1 : P;
 #pragma unroll
-        for (int p = 2; p < P; ++p) {
+        for (int p = 2; p < PL; ++p) {
             if (p < first) continue;
             const u32x4 t = pl[p] & carry;
             pl[p] ^= carry;
@@ -603,14 +610,15 @@ static hipError_t scan_dispatch_p(const ScanArgs& a, int planes, uint32_t slabs,
         case 7:  return scan_dispatch_nh<G, 7>(a, slabs, st);
         case 10: return scan_dispatch_nh<G, 10>(a, slabs, st);
         case 16: return scan_dispatch_nh<G, 16>(a, slabs, st);
+        case 20: return scan_dispatch_nh<G, 20>(a, slabs, st);
         case 24: return scan_dispatch_nh<G, 24>(a, slabs, st);
         default: return hipErrorInvalidValue;
     }
 }
-// queries one workgroup takes: 256 / g lane groups, one query each, or (wide-query form) min(8, 256 / g) groups per query
-uint32_t scan_queries_per_block(int g, bool wide_query) {
+// queries one workgroup takes: 256 / g lane groups, one query each, or (wide-query form) min(wq_groups, 256 / g) groups per query
+uint32_t scan_queries_per_block(int g, uint32_t wq_groups) {
     const uint32_t gpb = 256u / (uint32_t)g;
-    return wide_query ? gpb / (gpb < 8u ? gpb : 8u) : gpb;
+    return wq_groups ? gpb / (gpb < wq_groups ? gpb : wq_groups) : gpb;
 }
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st) {
     if (a.nq == 0 || a.n_batches == 0) return hipSuccess;

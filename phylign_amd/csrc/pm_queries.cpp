@@ -75,13 +75,16 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
         for (uint64_t b = 0; b < nb; ++b) blkq[(size_t)(b0 + b)] = (uint32_t)i;
     }
     // plane classes (counter width): stable partition of query ids by class
-    auto cls = [](uint32_t nt) { return nt <= 127 ? 0 : nt <= 1023 ? 1 : nt <= 65535 ? 2 : 3; };
+    auto cls = [](uint32_t nt) {
+        for (int c = 0; c < kNumClasses; ++c) if (nt < (1u << kPlaneClass[c])) return c;
+        return kNumClasses - 1;
+    };
     q->qmap.reserve(nq);
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < kNumClasses; ++c) {
         q->class_begin[c] = (uint32_t)q->qmap.size();
         for (size_t i = 0; i < nq; ++i) if (cls(q->n_terms[i]) == c) q->qmap.push_back((uint32_t)i);
     }
-    q->class_begin[4] = (uint32_t)q->qmap.size();
+    q->class_begin[kNumClasses] = (uint32_t)q->qmap.size();
 
     q->blkq.swap(blkq);
     // HBM copies are made on first use by a compute call (upload_queries): parsing, text

@@ -212,13 +212,13 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         ws->d_desc = nullptr; ws->h_desc = nullptr; ws->desc_cap = 0;
         ws->uploaded.clear();
         const size_t cap = std::max<size_t>(n_units, 64);
-        HIPCHK(hipMalloc((void**)&ws->d_desc, 5 * cap * sizeof(BatchDesc)));
-        HIPCHK(hipHostMalloc((void**)&ws->h_desc, 5 * cap * sizeof(BatchDesc), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void**)&ws->d_desc, (1 + kNumClasses) * cap * sizeof(BatchDesc)));
+        HIPCHK(hipHostMalloc((void**)&ws->h_desc, (1 + kNumClasses) * cap * sizeof(BatchDesc), hipHostMallocDefault));
         ws->desc_cap = cap;
     }
     // host image of all five slices: base descriptors, then per query class the block ranges of mixed launches
     const size_t dcap = ws->desc_cap;
-    memset(ws->h_desc, 0, 5 * dcap * sizeof(BatchDesc));
+    memset(ws->h_desc, 0, (1 + kNumClasses) * dcap * sizeof(BatchDesc));
     {
         size_t o = 0;
         for (auto& g : groups)
@@ -233,15 +233,17 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     }
     // wide-query form per (group, query class): when one lane group per query would leave the chip
     // mostly idle (few, long queries), min(8, 256 / lanes) groups share each query (k_scan<..., WQ>)
-    std::vector<uint8_t> use_wq(groups.size() * 4, 0);
+    // 0 = plain form, else the number of lane groups that may share a query (power of two, >= 8)
+    std::vector<uint32_t> use_wq(groups.size() * kNumClasses, 0);
     for (size_t gi = 0; gi < groups.size(); ++gi)
-        for (int c = 1; c < 4; ++c) {                       // classes of 128+ k-mers per query
+        for (int c = 1; c < kNumClasses; ++c) {            // classes of 128+ k-mers per query
             const uint32_t nqc = q->class_begin[c + 1] - q->class_begin[c];
             if (nqc == 0 || g_wide_query == 2) continue;
-            uint64_t waves = 0;
+            uint64_t waves = 0, lanes = 0;
             for (size_t u : groups[gi].members) {
-                const uint32_t qpb = scan_queries_per_block(units[u].ix->g, false);
+                const uint32_t qpb = scan_queries_per_block(units[u].ix->g, 0);
                 waves += 4ull * ((nqc + qpb - 1) / qpb) * units[u].ix->slabs;
+                lanes += (uint64_t)units[u].ix->g * units[u].ix->slabs;
             }
             // automatic: always when the plain form could not fill the chip (< 1.5 x the 4 096 wave slots of
             // 4 waves/SIMD); narrow rows (one query per lane group of 1 ... 16 lanes) measure faster in this
@@ -249,34 +251,40 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             // threshold bound (tools/variant_longq.sh)
             const bool few = waves < 6144;
             const bool narrow = groups[gi].g < 32;
-            use_wq[gi * 4 + (size_t)c] = (g_wide_query == 1 || few || (narrow && !g_threshold_bound)) ? 1 : 0;
+            if (!(g_wide_query == 1 || few || (narrow && !g_threshold_bound))) continue;
+            // groups per query: 8, or as many as it takes to put ~8 192 wavefronts on the chip (narrow rows
+            // with very few queries: up to a whole workgroup per query)
+            uint64_t want = (8192ull * 64 + (uint64_t)nqc * lanes - 1) / std::max<uint64_t>((uint64_t)nqc * lanes, 1);
+            uint32_t grp = 8;
+            while (grp < 256 && grp < want) grp <<= 1;
+            use_wq[gi * kNumClasses + (size_t)c] = grp;
         }
-    std::vector<uint32_t> mixed_blocks(groups.size() * 4, 0u);
+    std::vector<uint32_t> mixed_blocks(groups.size() * kNumClasses, 0u);
     {
         size_t desc_off = 0;
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             Group& g = groups[gi];
             if (g.g == 0)
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < kNumClasses; ++c) {
                     const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
                     if (e == b) continue;
                     uint64_t blk = 0;
                     BatchDesc* stage = ws->h_desc + (size_t)(1 + c) * dcap + desc_off;
                     for (size_t k = 0; k < g.members.size(); ++k) {
                         stage[k] = ws->h_desc[desc_off + k];
-                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes, use_wq[gi * 4 + (size_t)c] != 0);
+                        const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes, use_wq[gi * kNumClasses + (size_t)c]);
                         stage[k].block_begin = (uint32_t)blk;
                         blk += (e - b + qpb - 1) / qpb;
                     }
                     if (blk > 0x7FFFFFFFull) return fail(PM_ERANGE, "launch grid too large");
-                    mixed_blocks[gi * 4 + (size_t)c] = (uint32_t)blk;
+                    mixed_blocks[gi * kNumClasses + (size_t)c] = (uint32_t)blk;
                 }
             desc_off += g.members.size();
         }
     }
-    if (ws->uploaded.size() != 5 * dcap || memcmp(ws->uploaded.data(), ws->h_desc, 5 * dcap * sizeof(BatchDesc)) != 0) {
-        HIPCHK(hipMemcpyAsync(ws->d_desc, ws->h_desc, 5 * dcap * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
-        ws->uploaded.assign(ws->h_desc, ws->h_desc + 5 * dcap);
+    if (ws->uploaded.size() != (1 + kNumClasses) * dcap || memcmp(ws->uploaded.data(), ws->h_desc, (1 + kNumClasses) * dcap * sizeof(BatchDesc)) != 0) {
+        HIPCHK(hipMemcpyAsync(ws->d_desc, ws->h_desc, (1 + kNumClasses) * dcap * sizeof(BatchDesc), hipMemcpyHostToDevice, st));
+        ws->uploaded.assign(ws->h_desc, ws->h_desc + (1 + kNumClasses) * dcap);
     }
     // per-query minimum score, cached on the query set per threshold value
     if (nq && (!q->d_thr || q->thr_for != r->threshold)) {
@@ -289,7 +297,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     }
     // measurement option: sharded counters of the algorithmic bytes the scan really gathered
     size_t n_launch_max = 0;
-    for (auto& g : groups) { (void)g; n_launch_max += 4; }
+    for (auto& g : groups) { (void)g; n_launch_max += kNumClasses; }
     if (g_count_fetched) {
         if (!g_ctx.d_fetch) HIPCHK(hipMalloc((void**)&g_ctx.d_fetch, kFetchShards * sizeof(unsigned long long)));
         if (r->h_fetch) { hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
@@ -316,20 +324,21 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         { int rc = ensure_hashes(q, g.canon, g.nh, &d_h); if (rc) return rc; }
         uint64_t rowsum = 0;
         for (size_t u : g.members) rowsum += units[u].ix->info.row_bytes;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < kNumClasses; ++c) {
             const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
             if (e == b) continue;
             ScanArgs a;
             a.batches = ws->d_desc + desc_off; a.n_batches = (uint32_t)g.members.size();
             a.tiles = 0; a.total_blocks = 0;
-            a.wide_query = use_wq[(size_t)(&g - groups.data()) * 4 + (size_t)c]; a.pad2_ = 0;
+            a.wq_groups = use_wq[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
+            a.wide_query = a.wq_groups ? 1u : 0u;
             if (g.g > 0) {
-                const uint32_t qpb = scan_queries_per_block(g.g, a.wide_query != 0);
+                const uint32_t qpb = scan_queries_per_block(g.g, a.wq_groups);
                 a.tiles = (e - b + qpb - 1) / qpb;
             } else {
                 // mixed widths: the slice of this query class holds the per-batch workgroup ranges
                 a.batches = ws->d_desc + (size_t)(1 + c) * dcap + desc_off;
-                a.total_blocks = mixed_blocks[(size_t)(&g - groups.data()) * 4 + (size_t)c];
+                a.total_blocks = mixed_blocks[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
             }
             a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
             a.prune_n = r->nb_best;

@@ -265,7 +265,8 @@ def test_wide_query_form_is_bit_identical(pm, oracle, n_docs):
     """few long queries: several lane groups of a workgroup share one query (partial counts added
     through LDS).  Forced on (1), off (2) and automatic (0) give the same records, equal to the oracle."""
     rng = np.random.default_rng(900 + n_docs)
-    lens = [150, 158, 200, 700, 1053, 1054, 1500, 4000, 9000] + ([70000] if n_docs in (100, 4000) else [])
+    lens = [150, 158, 200, 700, 1053, 1054, 1500, 4000, 9000] + ([70000] if n_docs in (100, 4000) else []) + \
+        ([1048700] if n_docs == 100 else [])                    # 20- and 24-plane classes
     queries = [(f"w{i}", rand_seq(rng, L)) for i, L in enumerate(lens)] + [(f"x{i}", rand_seq(rng, 1300)) for i in range(9)]
     plant = []
     for qi in range(len(queries)):

@@ -169,7 +169,8 @@ def main():
     # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1: functional check of the N>1 code path
     # with several ranks on ONE GPU (RCCL refuses duplicate devices); never a reported number
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if os.environ.get("BENCH_SHARE_GPU"):
+    if os.environ.get("BENCH_SHARE_GPU") or local_rank >= torch.cuda.device_count():
+        # functional check on one GPU, or a launcher that already narrowed the visible devices per rank
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:

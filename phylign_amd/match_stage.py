@@ -125,7 +125,8 @@ def main(argv=None):
         import torch
         import torch.distributed as dist
         from .dist import gather_hits
-        if os.environ.get("PHYLIGN_SHARE_GPU"):                     # functional tests: several ranks, one GPU
+        if os.environ.get("PHYLIGN_SHARE_GPU") or local_rank >= max(torch.cuda.device_count(), 1):
+            # functional tests (several ranks, one GPU), or a launcher that narrowed the visible devices per rank
             local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

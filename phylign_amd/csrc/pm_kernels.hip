@@ -234,6 +234,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #ifndef PM_SCAN_TERMS
 #define PM_SCAN_TERMS 8              // k-mers (row gathers in flight per lane) per step: 8 or 4
 #endif
+#ifndef PM_SCAN_SHARE_ROWS
+#define PM_SCAN_SHARE_ROWS 1         // lanes of a group split the row-offset computation of a step (G >= 8, one hash)
+#endif
 #ifndef PM_SCAN_MIN_WAVES
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
     const uint32_t sub = WQ ? (gi & (ngrp - 1u)) : 0u;
     const uint32_t li = WQ ? (tile * gpb + gi) / ngrp : tile * gpb + gi;
     const uint32_t c = (uint32_t)lane & (g - 1u);
+    const uint32_t gfirst0 = (uint32_t)lane & ~(g - 1u);               // first lane of my group
     const uint32_t slab = blockIdx.y;
     const uint64_t boff = ((uint64_t)slab * g + c) * 16;   // byte offset of this lane's chunk
     const bool qv = li < a.nq;
@@ -345,9 +349,37 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
         u32x4 x[TS];
 #pragma unroll
         for (int i = 0; i < TS; ++i) x[i] = (u32x4)(0u);
+        // The lanes of a group all need the same TS row offsets.  With 8+ lanes per group and one hash
+        // function each lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett
+        // reduction instead of TS of each) and the group shares the offsets by ds_bpermute; every lane
+        // takes part in the exchange, alive or not (a disabled source lane would deliver 0).
+        constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8;
+        uint32_t my_lo = 0, my_hi = 0;
+        if constexpr (SHARE) {
+            const uint32_t i_mine = c & (uint32_t)(TS - 1);
+            if (qv && t0i + i_mine < nt) {
+                const uint64_t hm = a.hashes[(pb + b) * 8 + i_mine];         // [blk][hash 0][8]
+                const uint64_t off = mod_sig(hm, S, bm) * stride;
+                my_lo = (uint32_t)off; my_hi = (uint32_t)(off >> 32);
+            }
+        }
+        uint64_t roff[SHARE ? TS : 1];
+        if constexpr (SHARE) {
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                const uint32_t lo_ = (uint32_t)__shfl((int)my_lo, (int)(gfirst0 + (uint32_t)i), 64);
+                const uint32_t hi_ = (uint32_t)__shfl((int)my_hi, (int)(gfirst0 + (uint32_t)i), 64);
+                roff[i] = ((uint64_t)hi_ << 32) | lo_;
+            }
+        }
         if (active && t0i < nt && line_alive) {
             const uint32_t left = nt - t0i;           // >= 1 valid terms in this step
             if (a.fetch_count) nfetch += (left < (uint32_t)TS ? left : (uint32_t)TS) * nh;
+            if constexpr (SHARE) {
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+                    if ((uint32_t)i < left) x[i] = *reinterpret_cast<const u32x4*>(base + roff[i]);
+            } else
             for (uint32_t j = 0; j < nh; ++j) {
                 const u32x4* hj = hp + (size_t)(b * nh + j) * 4 + (sidx % SPB) * (TS / 2);
                 uint64_t h[TS];

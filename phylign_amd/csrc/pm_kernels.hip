@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
         // function each lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett
         // reduction instead of TS of each) and the group shares the offsets by ds_bpermute; every lane
         // takes part in the exchange, alive or not (a disabled source lane would deliver 0).
-        constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8;
+        // (only the 7-plane class of reads: the eight 64-bit offsets cost 16 registers, which the wider counter
+        // classes do not have to spare)
+        constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8 && P <= 7;
         uint32_t my_lo = 0, my_hi = 0;
         if constexpr (SHARE) {
             const uint32_t i_mine = c & (uint32_t)(TS - 1);

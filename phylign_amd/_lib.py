@@ -250,7 +250,7 @@ class Index:
         p = load().pm_index_doc_name(self._h, d, C.byref(n))
         if not p:
             raise IndexError(d)
-        return C.string_at(p, n.value).decode()
+        return C.string_at(p, n.value).decode(errors="replace")
 
     def read_row(self, row):
         out = np.zeros(self.info.row_bytes, dtype=np.uint8)

@@ -480,3 +480,42 @@ def test_parallel_gzip_members_decode_like_gzip_fast(tmp_path):
         assert gzip.open(p, "rb").read() == payload
         assert subprocess.run(["gzip", "-dc", str(p)], capture_output=True, check=True).stdout == payload
         assert not (tmp_path / "x.gz.tmp").exists()
+
+
+def test_header_reader_survives_corrupted_input(oracle):
+    """classic / compact header bytes with random flips, truncations and insertions: the product
+    reader either reports PM_EFORMAT / PM_EIO-style errors or returns a consistent handle -- it never
+    crashes and never reads outside the buffer (pm_index_load_header_mem needs no GPU)"""
+    from phylign_amd import _lib as pm
+    rng = np.random.default_rng(12)
+    names = [f"{i:05x}_SAM{i:06d}" for i in range(37)]
+    classic = bytes(oracle.make_index(31, 1, 500, 1, names))
+    compact = bytes(oracle.make_compact(31, 1, 16, [300, 200], [1, 2], names + [f"x_{i}" for i in range(100)]))
+    ok = bad = 0
+    for base in (classic, compact):
+        head_len = base.index(b"_INDEX", 20) + 6 if b"_INDEX" in base[20:] else len(base)
+        for _ in range(300):
+            b = bytearray(base[: head_len + int(rng.integers(0, 64))])
+            op = int(rng.integers(0, 4))
+            if op == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif op == 1:
+                b = b[: int(rng.integers(0, len(b)))]
+            elif op == 2:
+                p = int(rng.integers(0, len(b)))
+                b[p:p] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+            else:
+                p = int(rng.integers(18, min(len(b), 60)))
+                b[p:p + 8] = (int(rng.integers(0, 2**63))).to_bytes(8, "little")
+            try:
+                ix = pm.Index.load_header_mem(bytes(b))
+                info = ix.info
+                assert info.n_docs < 10**7 and info.has_matrix == 0
+                for d in range(min(info.n_docs, 5)):
+                    ix.doc_name(d)
+                ok += 1
+            except pm.PMError as e:
+                assert e.code in (-5, -4, -1), e
+                bad += 1
+    assert bad > 200 and ok + bad == 600

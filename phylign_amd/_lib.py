@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphylign_match.so")
+# PHYLIGN_MATCH_LIB: another build of the same library (e.g. the host code under AddressSanitizer for the CPU tests)
+LIB_PATH = os.environ.get("PHYLIGN_MATCH_LIB") or os.path.join(_HERE, "libphylign_match.so")
 
 PM_LAYOUT_AUTO, PM_LAYOUT_COMPACT, PM_LAYOUT_ALIGNED = 0, 1, 2
 PM_DOC_COUNT = 0xFFFFFFFF      # doc value of a "count record" (see include/phylign_match.h)

@@ -150,9 +150,9 @@ static int stream_matrix(Reader& rd, pm_index* ix, uint64_t rb, uint64_t S) {
     hipEvent_t ev[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) {
-            if (hbuf[i]) hipHostFree(hbuf[i]);
-            if (dbuf[i]) hipFree(dbuf[i]);
-            if (ev[i]) hipEventDestroy(ev[i]);
+            if (hbuf[i]) (void)hipHostFree(hbuf[i]);
+            if (dbuf[i]) (void)hipFree(dbuf[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
         }
     };
 #define LCHK(expr)                                                                        \
@@ -412,7 +412,7 @@ extern "C" int pm_index_plant(pm_index_t* ix, const uint64_t* rows, const uint32
     if (e == hipSuccess) e = hipMemcpyAsync(dd, docs, n * 4, hipMemcpyHostToDevice, g_ctx.stream);
     if (e == hipSuccess) e = launch_plant(ix->d_matrix, ix->info.stride, dr, dd, n, g_ctx.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-    hipFree(dr); if (dd) hipFree(dd);
+    (void)hipFree(dr); if (dd) (void)hipFree(dd);
     if (e != hipSuccess) return fail(PM_EHIP, "plant: %s", hipGetErrorString(e));
     return PM_OK;
 }
@@ -467,7 +467,7 @@ extern "C" int pm_index_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
     if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
     float f = 0;
     if (e == hipSuccess) e = hipEventElapsedTime(&f, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
     if (e != hipSuccess) return fail(PM_EHIP, "probe: %s", hipGetErrorString(e));
     *ms = f; *bytes = n_groups * lookups_per_group * ix->info.row_bytes;
     return PM_OK;
@@ -495,7 +495,7 @@ extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_doc
 extern "C" int pm_index_drop_matrix(pm_index_t* ix) {
     if (!ix) return fail(PM_EINVAL, "bad argument");
     bind_thread_quiet();
-    if (ix->d_matrix) { hipFree(ix->d_matrix); ix->d_matrix = nullptr; }
+    if (ix->d_matrix) { (void)hipFree(ix->d_matrix); ix->d_matrix = nullptr; }
     for (pm_index* p : ix->parts) pm_index_drop_matrix(p);
     ix->info.has_matrix = 0; ix->info.device_bytes = 0;
     return PM_OK;
@@ -532,7 +532,7 @@ extern "C" int pm_index_device(const pm_index_t* ix, int* device) {
 extern "C" void pm_index_free(pm_index_t* ix) {
     if (!ix) return;
     bind_thread_quiet();
-    if (ix->d_matrix) hipFree(ix->d_matrix);
+    if (ix->d_matrix) (void)hipFree(ix->d_matrix);
     for (pm_index* p : ix->parts) pm_index_free(p);
     delete ix;
 }

@@ -107,13 +107,13 @@ extern "C" int pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_t
 extern "C" void pm_queries_free(pm_queries_t* q) {
     if (!q) return;
     bind_thread_quiet();
-    if (g_ctx.ready && q->on_device) hipStreamSynchronize(g_ctx.stream);   // a search in flight may still read them
-    if (q->d_seq) hipFree(q->d_seq);
-    if (q->d_qd) hipFree(q->d_qd);
-    if (q->d_blkq) hipFree(q->d_blkq);
-    if (q->d_qmap) hipFree(q->d_qmap);
-    if (q->d_thr) hipFree(q->d_thr);
-    for (auto& h : q->hashes) if (h.d) hipFree(h.d);
+    if (g_ctx.ready && q->on_device) (void)hipStreamSynchronize(g_ctx.stream);   // a search in flight may still read them
+    if (q->d_seq) (void)hipFree(q->d_seq);
+    if (q->d_qd) (void)hipFree(q->d_qd);
+    if (q->d_blkq) (void)hipFree(q->d_blkq);
+    if (q->d_qmap) (void)hipFree(q->d_qmap);
+    if (q->d_thr) (void)hipFree(q->d_thr);
+    for (auto& h : q->hashes) if (h.d) (void)hipFree(h.d);
     delete q;
 }
 

@@ -50,22 +50,22 @@ extern "C" int pm_init(int device) {
 extern "C" void pm_shutdown(void) {
     if (!g_ctx.ready) return;
     bind_thread_quiet();
-    hipDeviceSynchronize();
-    hipStreamDestroy(g_ctx.stream);
-    hipStreamDestroy(g_ctx.copy_stream);
-    hipStreamDestroy(g_ctx.d2h_stream);
+    (void)hipDeviceSynchronize();
+    (void)hipStreamDestroy(g_ctx.stream);
+    (void)hipStreamDestroy(g_ctx.copy_stream);
+    (void)hipStreamDestroy(g_ctx.d2h_stream);
     for (Workspace* w : g_ctx.ws) {
-        if (w->d_cnt) hipFree(w->d_cnt);
-        if (w->h_cnt) hipHostFree(w->h_cnt);
-        if (w->d_desc) hipFree(w->d_desc);
-        if (w->h_desc) hipHostFree(w->h_desc);
-        for (auto e : w->events) hipEventDestroy(e);
-        if (w->done) hipEventDestroy(w->done);
+        if (w->d_cnt) (void)hipFree(w->d_cnt);
+        if (w->h_cnt) (void)hipHostFree(w->h_cnt);
+        if (w->d_desc) (void)hipFree(w->d_desc);
+        if (w->h_desc) (void)hipHostFree(w->h_desc);
+        for (auto e : w->events) (void)hipEventDestroy(e);
+        if (w->done) (void)hipEventDestroy(w->done);
         delete w;
     }
-    for (auto& b : g_ctx.free_hits) hipFree(b.p);
-    if (g_ctx.d_fetch) hipFree(g_ctx.d_fetch);
-    for (auto& b : g_ctx.free_pinned) hipHostFree(b.p);
+    for (auto& b : g_ctx.free_hits) (void)hipFree(b.p);
+    if (g_ctx.d_fetch) (void)hipFree(g_ctx.d_fetch);
+    for (auto& b : g_ctx.free_pinned) (void)hipHostFree(b.p);
     g_ctx = Ctx();
 }
 

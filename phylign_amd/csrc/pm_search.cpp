@@ -62,7 +62,7 @@ static void give_hit_buffer(HitBuf b) {
             g_ctx.free_hits.erase(g_ctx.free_hits.begin() + (long)small);
         }
     }
-    hipFree(b.p);
+    (void)hipFree(b.p);
 }
 
 // pinned host buffers (results on the host, staging): pooled, since pinning memory is slow
@@ -98,7 +98,7 @@ static void give_pinned(PinBuf b) {
             g_ctx.free_pinned.erase(g_ctx.free_pinned.begin() + (long)small);
         }
     }
-    hipHostFree(b.p);
+    (void)hipHostFree(b.p);
 }
 
 // One scan unit per classic index or per sub-index of a compact index.
@@ -141,7 +141,7 @@ static void result_release(pm_result* r) {
     give_hit_buffer(r->d_ord); r->d_ord = HitBuf{nullptr, 0};
     give_pinned(r->host); r->host = PinBuf{nullptr, 0};
     give_workspace(r->ws); r->ws = nullptr;
-    if (r->h_fetch) { hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
+    if (r->h_fetch) { (void)hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
 }
 
 // Enqueues hash + scan launches + the read-back of the record counters on the compute
@@ -207,8 +207,8 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         HIPCHK(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     }
     if (ws->desc_cap < n_units) {
-        if (ws->d_desc) hipFree(ws->d_desc);
-        if (ws->h_desc) hipHostFree(ws->h_desc);
+        if (ws->d_desc) (void)hipFree(ws->d_desc);
+        if (ws->h_desc) (void)hipHostFree(ws->h_desc);
         ws->d_desc = nullptr; ws->h_desc = nullptr; ws->desc_cap = 0;
         ws->uploaded.clear();
         const size_t cap = std::max<size_t>(n_units, 64);
@@ -300,7 +300,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     for (auto& g : groups) { (void)g; n_launch_max += kNumClasses; }
     if (g_count_fetched) {
         if (!g_ctx.d_fetch) HIPCHK(hipMalloc((void**)&g_ctx.d_fetch, kFetchShards * sizeof(unsigned long long)));
-        if (r->h_fetch) { hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
+        if (r->h_fetch) { (void)hipHostFree(r->h_fetch); r->h_fetch = nullptr; }
         HIPCHK(hipHostMalloc((void**)&r->h_fetch, std::max<size_t>(n_launch_max, 1) * kFetchShards * sizeof(unsigned long long), hipHostMallocDefault));
     }
 
@@ -398,7 +398,7 @@ extern "C" int pm_result_wait(pm_result_t* r) {
         // hit buffer too small: grow to the exact count and run the job again
         if (r->attempt >= 1) { r->pending = false; result_release(r); return fail(PM_EHIP, "hit count changed between runs"); }
         r->attempt++;
-        hipFree(r->d_hits); r->d_hits = nullptr; r->cap = 0;
+        (void)hipFree(r->d_hits); r->d_hits = nullptr; r->cap = 0;
         int rc = enqueue_search(r, cnt);
         if (rc) { r->pending = false; result_release(r); return rc; }
     }
@@ -442,7 +442,7 @@ extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_
     int rc = enqueue_search(r, want_cap);
     if (rc) {
         // whatever was queued before the failure must not outlive its buffers
-        hipStreamSynchronize(g_ctx.stream);
+        (void)hipStreamSynchronize(g_ctx.stream);
         result_release(r);
         delete r;
         return rc;
@@ -706,7 +706,7 @@ extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64
 extern "C" void pm_result_free(pm_result_t* r) {
     if (!r) return;
     bind_thread_quiet();
-    if (r->pending && r->ws) hipEventSynchronize(r->ws->done);      // the GPU may still write into the buffers
+    if (r->pending && r->ws) (void)hipEventSynchronize(r->ws->done);      // the GPU may still write into the buffers
     result_release(r);
     delete r;
 }

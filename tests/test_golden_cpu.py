@@ -519,3 +519,18 @@ def test_header_reader_survives_corrupted_input(oracle):
                 assert e.code in (-5, -4, -1), e
                 bad += 1
     assert bad > 200 and ok + bad == 600
+
+
+def test_oracle_xxh64_against_python_xxhash_live(oracle):
+    """beyond the committed known answers: random inputs of every length 0..80 and random seeds
+    against the python-xxhash wheel (libxxhash), when it is installed"""
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(99)
+    for n in list(range(0, 81)) + [127, 128, 129, 1000]:
+        for _ in range(4):
+            data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+            seed = int(rng.integers(0, 2**63))
+            assert oracle.xxh64(data, seed) == xxhash.xxh64(data, seed=seed).intdigest(), (n, seed)
+    for kmer in (b"ACGTACGTACGTACGTACGTACGTACGTACG", b"T" * 31, b"GATTACA" * 4 + b"GAT"):
+        for seed in range(4):
+            assert oracle.xxh64(kmer, seed) == xxhash.xxh64(kmer, seed=seed).intdigest()

@@ -240,6 +240,11 @@ void pm_hits_sort(pm_hit_t* hits, uint64_t n);
 int  pm_format_hits(const pm_index_t* idx, const pm_queries_t* q,
                     const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
                     int64_t nb_best_hits, char** text, size_t* len);
+/* plain cobs text with at most `limit` result lines per query and the header counting what is
+ * printed: `cobs query -l limit` (0 = all; Phylign never passes -l) */
+int  pm_format_hits_limit(const pm_index_t* idx, const pm_queries_t* q,
+                          const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                          uint64_t limit, char** text, size_t* len);
 /* one-shot: what `cobs query -i INDEX -f FASTA -t T` prints */
 int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
                    double threshold, int64_t nb_best_hits, char** text, size_t* len);

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("pm_result_hits_host", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_result_free", None, [_P]),
     ("pm_format_hits", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pm_format_hits_limit", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     ("pm_merge_add", C.c_int, [_P, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
     ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -431,6 +432,16 @@ def format_hits(index: Index, queries: Queries, hits, slot=0, nb_best_hits=-1) -
     t, n = _P(), C.c_size_t()
     _chk(load().pm_format_hits(index._h, queries._h, hits.ctypes.data, hits.size, slot, nb_best_hits,
                                C.byref(t), C.byref(n)))
+    out = C.string_at(t.value, n.value)
+    load().pm_free(t)
+    return out
+
+
+def format_hits_limit(index: Index, queries: Queries, hits, slot=0, limit=0) -> bytes:
+    """plain cobs text with at most `limit` result lines per query (`cobs query -l`)"""
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    t, n = _P(), C.c_size_t()
+    _chk(load().pm_format_hits_limit(index._h, queries._h, hits.ctypes.data, hits.size, slot, limit, C.byref(t), C.byref(n)))
     out = C.string_at(t.value, n.value)
     load().pm_free(t)
     return out

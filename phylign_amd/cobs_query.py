@@ -46,8 +46,8 @@ def run_query(args, out=None):
     out = out or sys.stdout.buffer
     if len(args.index) != 1:
         raise SystemExit("error: exactly one -i index is supported (Phylign passes one per batch)")
-    if args.limit:
-        raise SystemExit("error: -l/--limit is not supported; Phylign never passes it (use --nb-best-hits)")
+    if args.limit and (args.server or args.nb_best_hits is not None):
+        raise SystemExit("error: -l/--limit cannot be combined with --server or --nb-best-hits")
     size_hint = args.index_sizes[0] if args.index_sizes else 0
     if args.server:
         from .server import request
@@ -66,7 +66,14 @@ def run_query(args, out=None):
     with open(args.query_file, "rb") as f:
         fasta = f.read()
     nb = -1 if args.nb_best_hits is None else max(args.nb_best_hits, 0)
-    out.write(pm.query_text(ix, fasta, args.threshold, nb_best_hits=nb))
+    if args.limit > 0:
+        # -l N: the GPU keeps the N best + ties per query, the formatter prints exactly N
+        q = pm.Queries(fasta, term_size=ix.info.term_size)
+        res = pm.search([ix], q, args.threshold, nb_best_hits=args.limit)
+        out.write(pm.format_hits_limit(ix, q, res.hits(), limit=args.limit))
+        res.free()
+    else:
+        out.write(pm.query_text(ix, fasta, args.threshold, nb_best_hits=nb))
     out.flush()
     ix.free()
 

@@ -20,7 +20,7 @@ static inline void append_tab_uint_nl(std::string& out, uint64_t v) {     // "\t
 // formats the records of queries [qa, qb) (a slice of one slot's ordered records) into `out`;
 // returns PM_OK or an error code with the message in `err`
 static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_hit_t* mine, size_t n_mine,
-                              size_t qa, size_t qb, int64_t nb_best, std::string& out, std::string& err) {
+                              size_t qa, size_t qb, int64_t nb_best, uint64_t limit, std::string& out, std::string& err) {
     char msg[512];
     size_t p = (size_t)(std::lower_bound(mine, mine + n_mine, (uint32_t)qa,
                                          [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
@@ -33,6 +33,11 @@ static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_
             // passed -t) or raw device runs of several column slabs / sub-indexes (they add up)
             total = 0;
             while (p < e && mine[p].doc == PM_DOC_COUNT) { total += mine[p].score; ++p; }
+        }
+        if (limit && nb_best < 0) {
+            // `cobs query -l N`: the N best results (the list is ordered), and the header counts what is printed
+            if (e - p > limit) e = p + (size_t)limit;
+            total = e - p;
         }
         if (!q->headerless[qi]) out.push_back('*');
         else if (nb_best >= 0) {    // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
@@ -76,13 +81,28 @@ static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_
             }
         }
         p = e;
+        while (p < n_mine && mine[p].query == qi) ++p;          // records past a -l limit
     }
     return PM_OK;
 }
 
+static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                       int64_t nb_best, uint64_t limit, char** text, size_t* len);
+
 extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
                               const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
                               int64_t nb_best, char** text, size_t* len) {
+    return format_impl(ix, q, hits, n_hits, slot, nb_best, 0, text, len);
+}
+// plain cobs text with at most `limit` result lines per query: `cobs query -l limit` (0 = all)
+extern "C" int pm_format_hits_limit(const pm_index_t* ix, const pm_queries_t* q,
+                                    const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                                    uint64_t limit, char** text, size_t* len) {
+    return format_impl(ix, q, hits, n_hits, slot, -1, limit, text, len);
+}
+
+static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                       int64_t nb_best, uint64_t limit, char** text, size_t* len) {
     if (!ix || !q || (!hits && n_hits) || !text || !len) return fail(PM_EINVAL, "bad argument");
     const size_t nq = q->headers.size();
     // records as pm_result_hits_* deliver them are already in line order: the slot's records are
@@ -123,7 +143,7 @@ extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
     }
     auto work = [&](size_t t) {
         parts[t].reserve((size_t)((double)(n_mine * 28 + nq * 24) / (double)nt * 1.1) + 64);
-        rcs[t] = format_query_range(ix, q, mine, n_mine, cutq[t], cutq[t + 1], nb_best, parts[t], errs[t]);
+        rcs[t] = format_query_range(ix, q, mine, n_mine, cutq[t], cutq[t + 1], nb_best, limit, parts[t], errs[t]);
     };
     if (nt == 1) work(0);
     else {

@@ -90,6 +90,27 @@ def test_cobs_query_cli_plain_file(pm, oracle, tmp_path):
     assert r.returncode == 1 and b"cannot open index" in r.stderr
 
 
+@pytest.mark.parametrize("limit", [1, 3, 50])
+def test_cobs_query_limit(pm, oracle, tmp_path, limit):
+    """`cobs query -l N`: the N best results per query, header = lines printed (oracle: num_results)"""
+    index, fasta, _ = _case(oracle, seed=24, n_docs=664, S=20000)
+    p = tmp_path / "i.cobs_classic"
+    p.write_bytes(bytes(index))
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(fasta)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for thr in ("0.7", "0.0"):
+        r = subprocess.run([sys.executable, "-m", "phylign_amd.cobs_query", "query", "-t", thr, "-l", str(limit),
+                            "-i", str(p), "-f", str(fa)], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == oracle.query_file(index, fasta, float(thr), limit)
+    ix = pm.Index.load_mem(index)
+    q = pm.Queries(fasta)
+    hits = pm.search([ix], q, 0.7).hits()                          # uncut records format the same
+    assert pm.format_hits_limit(ix, q, hits, limit=limit) == oracle.query_file(index, fasta, 0.7, limit)
+    assert pm.format_hits_limit(ix, q, hits, limit=0) == oracle.query_file(index, fasta, 0.7)
+
+
 def test_match_to_filter_dropin(pm, oracle, tmp_path):
     """03_match files of three batches feed the 04_filter consumer (Snakefile:490-520)."""
     from phylign_amd import filter_queries as F

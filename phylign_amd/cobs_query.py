@@ -10,8 +10,8 @@ pipe such as /dev/fd/63.  `--load-complete` and `-T` are accepted and ignored
 (the index is always fully resident in HBM; results never depended on the
 thread count).  Extensions: `--nb-best-hits N` fuses `postprocess_cobs.py -n N`
 (Snakefile:425 / :467) into the same process; `--device D` picks the GPU;
-`--server SOCK` (or PHYLIGN_MATCH_SERVER) sends the job to a resident-index
-server (phylign_amd/server.py) -- then INDEX must be a path the server can open
+`--server SOCK[,SOCK...]` (or PHYLIGN_MATCH_SERVER) sends the job to a resident-index
+server (phylign_amd/server.py; with one socket per GPU a batch always goes to the same one) -- then INDEX must be a path the server can open
 (the .xz itself is fine, the server decodes it once and keeps it in HBM).
 Any failure exits non-zero with the reason on stderr (Snakefile:142 runs rules
 under `set -euo pipefail`; scripts/benchmark.py:56-61 re-raises).
@@ -41,6 +41,21 @@ def build_parser():
     return ap
 
 
+def pick_server(servers, index_path):
+    """`--server` may list one socket per GPU, comma separated: a batch always goes to the same one
+    (CRC-32 of its file name), so each server of an 8-GPU node keeps its own eighth of the 661k
+    indexes resident -- the whole database (1.06 TB decompressed) fits 8 x 288 GB, not one GPU."""
+    import zlib
+    socks = [s for s in servers.split(",") if s]
+    if len(socks) <= 1:
+        return socks[0] if socks else servers
+    name = os.path.basename(index_path)
+    for ext in (".xz", ".cobs_classic", ".cobs_compact"):
+        if name.endswith(ext):
+            name = name[: -len(ext)]
+    return socks[zlib.crc32(name.encode()) % len(socks)]
+
+
 def run_query(args, out=None):
     from . import _lib as pm
     out = out or sys.stdout.buffer
@@ -53,7 +68,7 @@ def run_query(args, out=None):
         from .server import request
         with open(args.query_file, "rb") as f:
             fasta = f.read()
-        head, body = request(args.server, {"op": "query", "index": os.path.abspath(args.index[0]), "index_size": size_hint,
+        head, body = request(pick_server(args.server, args.index[0]), {"op": "query", "index": os.path.abspath(args.index[0]), "index_size": size_hint,
                                            "fasta_len": len(fasta), "threshold": args.threshold,
                                            "nb_best_hits": args.nb_best_hits}, fasta)
         if not head.get("ok"):

@@ -534,3 +534,19 @@ def test_oracle_xxh64_against_python_xxhash_live(oracle):
     for kmer in (b"ACGTACGTACGTACGTACGTACGTACGTACG", b"T" * 31, b"GATTACA" * 4 + b"GAT"):
         for seed in range(4):
             assert oracle.xxh64(kmer, seed) == xxhash.xxh64(kmer, seed=seed).intdigest()
+
+
+def test_server_routing_is_stable_and_spreads_the_661k_batches():
+    """one resident-index server per GPU: a batch always goes to the same socket, whatever its
+    extension, and the 305 batches of the 661k collection fit 8 x 288 GB with that map"""
+    from phylign_amd import workload as W
+    from phylign_amd.cobs_query import pick_server
+    socks = ",".join(f"/tmp/pm{i}.sock" for i in range(8))
+    shapes = W.load_shapes()
+    load = {}
+    for s in shapes:
+        a = pick_server(socks, f"cobs/{s.batch}.cobs_classic.xz")
+        assert a == pick_server(socks, f"/elsewhere/{s.batch}.cobs_classic") == pick_server(socks, s.batch)
+        load[a] = load.get(a, 0) + s.index_bytes * 1.1            # line-aligned rows cost a few percent more
+    assert len(load) == 8 and max(load.values()) < 0.85 * 288e9, {k: round(v / 1e9) for k, v in load.items()}
+    assert pick_server("/tmp/one.sock", "x.xz") == "/tmp/one.sock"

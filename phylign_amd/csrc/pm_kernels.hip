@@ -808,11 +808,59 @@ __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict_
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;   // keeps the loads alive
 }
+// Cache-policy flavours of the same gather (PM_PROBE_FLAVOR = 1 ... 5): does a gather that needs 16-64 bytes of a
+// 128-byte line cost less on the fabric when it bypasses / streams through the caches?  F: 1 = nt, 2 = sc1,
+// 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc0.  Inline asm: the waits are explicit (the compiler does not track these loads).
+#define PM_PROBE_LOAD(F, dst, ptr)                                                                                    \
+    do {                                                                                                              \
+        if constexpr (F == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory");          \
+        else if constexpr (F == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory");    \
+        else if constexpr (F == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(ptr) : "memory"); \
+        else if constexpr (F == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(dst) : "v"(ptr) : "memory"); \
+        else asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(dst) : "v"(ptr) : "memory");                    \
+    } while (0)
+template <int G, int F>
+__global__ __launch_bounds__(256) void k_probe_flavor(const uint8_t* __restrict__ matrix, uint64_t stride,
+                                                       uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const uint32_t c = lane % G;
+    u32x4 acc = (u32x4)(0u);
+    uint64_t state = splitmix64(group * 0x9E3779B97F4A7C15ULL + 1);
+    const uint64_t coff = ((uint64_t)c * 16 < stride) ? (uint64_t)c * 16 : 0;     // every lane loads (asm loads are unconditional)
+    for (uint64_t i = 0; i < lookups_per_group; i += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+            uint64_t r = __umul64hi(state, n_rows);
+            const uint8_t* p = matrix + r * stride + coff;
+            PM_PROBE_LOAD(F, v[k], p);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+template <int G>
+static void probe_launch_flavor(int flavor, dim3 grid, hipStream_t st, const uint8_t* matrix, uint64_t stride,
+                                uint64_t n_rows, uint64_t per, uint32_t* sink) {
+    switch (flavor) {
+        case 1: hipLaunchKernelGGL((k_probe_flavor<G, 1>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
+        case 2: hipLaunchKernelGGL((k_probe_flavor<G, 2>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
+        case 3: hipLaunchKernelGGL((k_probe_flavor<G, 3>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
+        case 4: hipLaunchKernelGGL((k_probe_flavor<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
+        default: hipLaunchKernelGGL((k_probe_flavor<G, 5>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
+    }
+}
 template <int G>
 static void probe_launch_u(int unroll, dim3 grid, hipStream_t st, const uint8_t* matrix, uint64_t stride,
                            uint64_t n_rows, uint64_t per, uint32_t* sink) {
     int mode = 0;
     if (const char* m = getenv("PM_PROBE_MODE")) mode = atoi(m);
+    if (const char* f = getenv("PM_PROBE_FLAVOR")) if (atoi(f) > 0) { probe_launch_flavor<G>(atoi(f), grid, st, matrix, stride, n_rows, per, sink); return; }
     if (unroll == 4)       hipLaunchKernelGGL((k_probe_gather<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
     else if (unroll == 16) hipLaunchKernelGGL((k_probe_gather<G, 16>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
     else                   hipLaunchKernelGGL((k_probe_gather<G, 8>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);

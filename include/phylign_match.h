@@ -256,9 +256,18 @@ int  pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out);
 /* adds the 03_match content of one batch: records of `slot` (count records are
  * skipped), post-filtered with nb_best_hits like pm_format_hits (>= 0) or taken
  * as they are (< 0); `batch` is the batch name of the file name
- * "<batch>____<qfile>.gz" (scripts/filter_queries.py:44), the tie-break after the score. */
+ * "<batch>____<qfile>.gz" (scripts/filter_queries.py:44), the tie-break after the score.  The
+ * merge copies the names it needs: the index may be freed right after the call.  Calls may come
+ * from several threads (serialised inside). */
 int  pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* idx,
                   const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits);
+/* What the merge holds so far, as hit records {query, doc, score, slot = ordinal of the pm_merge_add
+ * call that brought the batch} ordered by (slot, query, score desc, doc asc): one rank's share of the
+ * 04_filter result.  The ranks of a multi-GPU stage gather these (the single RCCL gather at the end)
+ * and rank 0 adds them again batch by batch with nb_best_hits < 0: the `keep` best (+ ties) of the
+ * union are among the `keep` best (+ ties) of every part, so the result equals the one-process merge
+ * (scripts/filter_queries.py:123-156 prunes the same way file after file).  *hits malloc'd, pm_free(). */
+int  pm_merge_export(const pm_merge_t* m, pm_hit_t** hits, uint64_t* n);
 /* ">qname ref1,ref2,...\nseq\n" per query in FASTA order; *text malloc'd, pm_free() */
 int  pm_merge_emit(const pm_merge_t* m, char** text, size_t* len);
 void pm_merge_free(pm_merge_t* m);

@@ -96,6 +96,7 @@ SYMBOLS = [
     ("pm_format_hits_limit", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     ("pm_merge_add", C.c_int, [_P, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
+    ("pm_merge_export", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_free", None, [_P]),
     ("pm_query_text", C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_double, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -400,6 +401,15 @@ class Merge:
     def add(self, batch: str, index: Index, hits, slot=0, nb_best_hits=-1):
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
         _chk(load().pm_merge_add(self._h, batch.encode(), index._h, hits.ctypes.data, hits.size, slot, nb_best_hits))
+
+    def export(self):
+        """what is kept so far as a HIT_DTYPE array (slot = ordinal of the add() call that brought the batch)"""
+        p, n = _P(), C.c_uint64()
+        _chk(load().pm_merge_export(self._h, C.byref(p), C.byref(n)))
+        buf = (C.c_char * (n.value * HIT_DTYPE.itemsize)).from_address(p.value) if n.value else b""
+        out = np.frombuffer(buf, dtype=HIT_DTYPE).copy()
+        load().pm_free(p)
+        return out
 
     def emit(self) -> bytes:
         t, n = _P(), C.c_size_t()

@@ -192,15 +192,40 @@ extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len
 // ">qname ref1,ref2,...\nseq".  What is merged per batch is what the 03_match
 // file of that batch holds, i.e. the hit list after the per-batch post-filter
 // (scripts/postprocess_cobs.py:21-39 with -n nb_best_hits).
-struct MergeItem { uint32_t kmers; uint32_t batch; std::string ref; };
+// An item is 12 bytes: the reference name ("what follows the first '_'") is looked up in the merge's
+// own copy of the batch's name table when items are ordered or printed, so a million queries with a
+// hundred matches each cost ~1.2 GB, not a std::string apiece, and the index may be freed right after
+// pm_merge_add (match_stage streams batches through HBM and never keeps their records).
+struct MergeItem { uint32_t kmers, batch, doc; };
+struct MergeBatch {
+    std::string name;                   // batch name of "<batch>____<qfile>.gz"
+    std::string refs;                   // reference names, '\0' separated
+    std::vector<uint32_t> ref_off;      // n_docs + 1
+};
 struct pm_merge {
     const pm_queries* q = nullptr;
     uint32_t keep = 0;
-    std::vector<std::string> batches;
+    std::vector<MergeBatch> batches;
     std::map<std::string, uint32_t> by_name;        // query name (first word) -> record index
     std::vector<std::string> qnames;
     std::vector<std::vector<MergeItem>> items;
     std::vector<uint32_t> floor_;
+    std::mutex mu;                                  // pm_merge_add may be called from a consumer thread pool
+    const char* ref(const MergeItem& it, size_t* len) const {
+        const MergeBatch& b = batches[it.batch];
+        *len = (size_t)(b.ref_off[it.doc + 1] - b.ref_off[it.doc] - 1);
+        return b.refs.data() + b.ref_off[it.doc];
+    }
+    bool less(const MergeItem& a, const MergeItem& b) const {       // (-kmers, batch, ref): scripts/filter_queries.py:135
+        if (a.kmers != b.kmers) return a.kmers > b.kmers;
+        if (a.batch != b.batch) { const int c = batches[a.batch].name.compare(batches[b.batch].name); if (c) return c < 0; }
+        size_t la, lb;
+        const char* ra = ref(a, &la); const char* rb = ref(b, &lb);
+        const int c = memcmp(ra, rb, std::min(la, lb));
+        if (c) return c < 0;
+        if (la != lb) return la < lb;
+        return a.batch < b.batch;
+    }
 };
 
 extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
@@ -223,21 +248,48 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
                             const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
     if (!m || !batch || !ix || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
     const size_t nq = m->q->headers.size();
-    std::vector<pm_hit_t> mine;
-    for (uint64_t i = 0; i < n_hits; ++i)
-        if (hits[i].slot == slot && hits[i].doc != PM_DOC_COUNT) {
-            if (hits[i].query >= nq || hits[i].doc >= ix->info.n_docs)
-                return fail(PM_EINVAL, "hit record out of range for batch %s", batch);
-            mine.push_back(hits[i]);
-        }
-    order_hits(mine.data(), mine.size());
+    // the slot's records: a contiguous slice when the input is ordered (what pm_result_hits_* deliver),
+    // else copied out and ordered
+    std::vector<pm_hit_t> copy;
+    const pm_hit_t* mine = hits; size_t n_mine = 0;
+    if (std::is_sorted(hits, hits + n_hits, [](const pm_hit_t& a, const pm_hit_t& b) { return hit_less(a, b); })) {
+        const pm_hit_t* lo = std::lower_bound(hits, hits + n_hits, slot, [](const pm_hit_t& h, uint32_t v) { return h.slot < v; });
+        const pm_hit_t* hi = std::upper_bound(lo, hits + n_hits, slot, [](uint32_t v, const pm_hit_t& h) { return v < h.slot; });
+        mine = lo; n_mine = (size_t)(hi - lo);
+    } else {
+        for (uint64_t i = 0; i < n_hits; ++i) if (hits[i].slot == slot) copy.push_back(hits[i]);
+        order_hits(copy.data(), copy.size());
+        mine = copy.data(); n_mine = copy.size();
+    }
+    for (size_t i = 0; i < n_mine; ++i)
+        if (mine[i].query >= nq || (mine[i].doc != PM_DOC_COUNT && mine[i].doc >= ix->info.n_docs))
+            return fail(PM_EINVAL, "hit record out of range for batch %s", batch);
+    std::lock_guard<std::mutex> lk(m->mu);
+    // reference names of this batch ("<rnd>_<ref>" -> "<ref>", exactly one '_': scripts/filter_queries.py:64);
+    // a malformed name is an error only if a kept record uses it, like the consumer's tuple unpacking
     const uint32_t bid = (uint32_t)m->batches.size();
-    m->batches.push_back(batch);
+    m->batches.emplace_back();
+    MergeBatch& mb = m->batches.back();
+    mb.name = batch;
+    mb.ref_off.resize((size_t)ix->info.n_docs + 1);
+    std::vector<uint8_t> bad_name((size_t)ix->info.n_docs, 0);
+    for (uint32_t d = 0; d < ix->info.n_docs; ++d) {
+        const char* nm = ix->names_blob.data() + ix->name_off[d];
+        const size_t nl = (size_t)(ix->name_off[d + 1] - ix->name_off[d] - 1);
+        const char* us = (const char*)memchr(nm, '_', nl);
+        mb.ref_off[d] = (uint32_t)mb.refs.size();
+        if (!us || memchr(us + 1, '_', nl - (size_t)(us + 1 - nm))) bad_name[d] = 1;
+        else mb.refs.append(us + 1, nl - (size_t)(us + 1 - nm));
+        mb.refs.push_back('\0');
+    }
+    mb.ref_off[ix->info.n_docs] = (uint32_t)mb.refs.size();
     size_t p = 0;
-    while (p < mine.size()) {
+    while (p < n_mine) {
         size_t e = p;
         const uint32_t qi = mine[p].query;
-        while (e < mine.size() && mine[e].query == qi) ++e;
+        while (e < n_mine && mine[e].query == qi) ++e;
+        while (p < e && mine[p].doc == PM_DOC_COUNT) ++p;            // count records carry no match
+        if (p == e) continue;
         // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
         // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
         const std::string& h = m->q->headers[qi];
@@ -247,6 +299,7 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
         if (it == m->by_name.end()) return fail(PM_EINVAL, "query '%s' of batch %s is not in the query file", key.c_str(), batch);
         const uint32_t target = it->second;
         std::vector<MergeItem>& v = m->items[target];
+        const size_t before = v.size();
         uint32_t nth = 0;
         for (size_t i = p; i < e; ++i) {
             if (nb_best >= 0) {                          // per-batch post-filter, same rule as pm_format_hits
@@ -254,28 +307,45 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
                 if (rank == nb_best) nth = mine[i].score;
                 if (rank > nb_best && mine[i].score != nth) continue;
             }
-            const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
-            const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
-            const char* us = (const char*)memchr(nm, '_', nl);
-            if (!us || memchr(us + 1, '_', nl - (size_t)(us + 1 - nm)))
-                return fail(PM_EINVAL, "document name '%.*s' must hold exactly one '_' (scripts/filter_queries.py:64)", (int)nl, nm);
-            if (mine[i].score >= m->floor_[target])
-                v.push_back({mine[i].score, bid, std::string(us + 1, nl - (size_t)(us + 1 - nm))});
+            if (bad_name[mine[i].doc]) {
+                const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
+                return fail(PM_EINVAL, "document name '%s' must hold exactly one '_' (scripts/filter_queries.py:64)", nm);
+            }
+            if (mine[i].score >= m->floor_[target]) v.push_back({mine[i].score, bid, mine[i].doc});
         }
-        std::sort(v.begin(), v.end(), [&](const MergeItem& a, const MergeItem& b) {
-            if (a.kmers != b.kmers) return a.kmers > b.kmers;
-            if (a.batch != b.batch) return m->batches[a.batch] < m->batches[b.batch];
-            return a.ref < b.ref;
-        });
-        if (v.size() > m->keep) {
-            if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
-            size_t cut = m->keep;
-            m->floor_[target] = v[cut - 1].kmers;
-            while (cut < v.size() && v[cut].kmers == m->floor_[target]) ++cut;
-            v.resize(cut);
+        if (v.size() != before) {
+            std::sort(v.begin(), v.end(), [&](const MergeItem& a, const MergeItem& b) { return m->less(a, b); });
+            if (v.size() > m->keep) {
+                if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
+                size_t cut = m->keep;
+                m->floor_[target] = v[cut - 1].kmers;
+                while (cut < v.size() && v[cut].kmers == m->floor_[target]) ++cut;
+                v.resize(cut);
+                v.shrink_to_fit();
+            }
         }
         p = e;
     }
+    return PM_OK;
+}
+
+// What is kept so far as hit records {query, doc, score, slot = number of the pm_merge_add call that
+// brought the batch}, ordered by (slot, query, score desc, doc asc): a rank's share of the 04_filter
+// merge, ready to be gathered (RCCL) and added again on rank 0 -- the best `keep` (+ ties) of the
+// union are among the best `keep` (+ ties) of every part.
+extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n) {
+    pm_merge* m = const_cast<pm_merge*>(m_);
+    if (!m || !out || !n) return fail(PM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    uint64_t total = 0;
+    for (auto& v : m->items) total += v.size();
+    pm_hit_t* buf = (pm_hit_t*)malloc(std::max<uint64_t>(total, 1) * sizeof(pm_hit_t));
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    uint64_t o = 0;
+    for (size_t qi = 0; qi < m->items.size(); ++qi)
+        for (const MergeItem& it : m->items[qi]) buf[o++] = pm_hit_t{(uint32_t)qi, it.doc, it.kmers, it.batch};
+    order_hits(buf, total);
+    *out = buf; *n = total;
     return PM_OK;
 }
 
@@ -292,7 +362,11 @@ extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
         seen[rec] = 1;
         out.push_back('>'); out += m->qnames[i]; out.push_back(' ');
         const std::vector<MergeItem>& v = m->items[rec];
-        for (size_t k = 0; k < v.size(); ++k) { if (k) out.push_back(','); out += v[k].ref; }
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (k) out.push_back(',');
+            size_t rl; const char* r = m->ref(v[k], &rl);
+            out.append(r, rl);
+        }
         out.push_back('\n');
         out.append(q->seqs, (size_t)q->seq_off[rec], (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]));
         out.push_back('\n');

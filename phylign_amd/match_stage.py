@@ -8,15 +8,28 @@ decompress_and_run_cobs, then Snakefile:490-520 rule translate_matches).
         --out-dir intermediate/03_match [--filter-out intermediate/04_filter/Q.fa]
     python -m torch.distributed.run --nproc-per-node 8 ... -m phylign_amd.match_stage ...   # one rank per GPU
 
-Per rank: its batches (static LPT map on index bytes) are decoded by a pool of
-`xzcat` pipes and streamed into HBM while the GPU searches the previous ones;
-every batch yields `<out-dir>/<batch>____<qfile>.gz` with exactly the bytes of
+Per rank (static batch -> rank map on scan cost, workload.assign_named):
+
+  loaders    a pool of `xzcat` pipes decodes the rank's batches and streams them into HBM, admitted
+             to an HBM budget in submission order;
+  consumer   takes EVERY batch that is resident by now as one group and queues ONE fused search for
+             it (pm_search_async: one scan launch per row-width class x counter-width class, whatever
+             the number of batches -- the path bench.py measures); while the GPU scans group i + 1 the
+             host finishes group i: per batch the cobs text after the post-filter
+             (pm_format_hits(nb_best_hits)), `gzip --fast` members deflated in parallel, and the
+             batch's records streamed into the native 04_filter merge (pm_merge_add) -- then the
+             records and the matrix are dropped.  Host memory holds one group's records plus the
+             merge state (12 bytes per kept match), never every batch's hit list.
+  end        with --filter-out every rank exports what its merge kept (pm_merge_export), ONE gather
+             (RCCL) brings the exports to rank 0, which adds them again and writes the FASTA
+             (scripts/filter_queries.py semantics).
+
+Every batch yields `<out-dir>/<batch>____<qfile>.gz` with exactly the bytes of
 `run_cobs_streaming.sh ... | postprocess_cobs.py -n N | gzip` after gunzip.
-With --filter-out the pruned hit records are gathered to rank 0 (RCCL) and
-merged natively into the 04_filter FASTA (scripts/filter_queries.py semantics).
+The last line on stderr is a JSON report with match-only, format, gzip, merge and
+end-to-end times.
 """
 import argparse
-import gzip
 import json
 import os
 import subprocess
@@ -55,10 +68,9 @@ def lpt(weights, n):
 
 class Admission:
     """HBM budget for decoded-but-not-yet-searched indexes.  Loaders are admitted strictly in
-    submission order (a ticket counter): the consumer drains batches in that same order and a
-    reservation is only returned after its batch was searched, so a later batch must never hold
-    the budget an earlier one is still waiting for.  A batch larger than the whole budget is
-    admitted once nothing else is resident."""
+    submission order (a ticket counter) and a reservation is only returned after its batch was
+    searched, so a later batch never holds the budget an earlier one is still waiting for.  A
+    batch larger than the whole budget is admitted once nothing else is resident."""
 
     def __init__(self, budget):
         self.budget, self.resident, self.next_ticket = float(budget), 0.0, 0
@@ -101,10 +113,198 @@ def open_index_stream(cobs_dir, batch):
     return p.stdout, p
 
 
+class FileSource:
+    """indexes read from <cobs-dir>/<batch>.cobs_classic[.xz] (what the reference's rules read)"""
+
+    def __init__(self, pm, cobs_dir, sizes):
+        self.pm, self.cobs_dir, self.sizes = pm, cobs_dir, sizes
+
+    def need(self, batch):
+        # what the loader may allocate at most: the line-aligned layout never needs more than twice
+        # the file's bytes (a 65-byte row becomes 128), plus the two 32 MiB staging chunks
+        return 2.0 * float(self.sizes.get(batch, 0)) + (128 << 20)
+
+    def load(self, batch):
+        fobj, proc = open_index_stream(self.cobs_dir, batch)
+        try:
+            ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0))
+        finally:
+            fobj.close()
+            if proc is not None and proc.wait() != 0:
+                raise RuntimeError(f"xzcat failed on batch {batch}")
+        return ix
+
+
+class SynthSource:
+    """measurement / test aid: 661k-shaped synthetic signatures generated in HBM in place
+    of files; `plant` maps a batch name to (rows, docs) bit positions to set"""
+
+    def __init__(self, pm, shapes, seed=661, plant=None):
+        self.pm, self.by_name, self.seed, self.plant = pm, {s.batch: s for s in shapes}, seed, plant or {}
+
+    def need(self, batch):
+        s = self.by_name[batch]
+        return 2.0 * s.signature_size * s.row_bytes + (16 << 20)
+
+    def load(self, batch):
+        s = self.by_name[batch]
+        ix = self.pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, self.seed)
+        if batch in self.plant:
+            ix.plant(*self.plant[batch])
+        return ix
+
+
+def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
+              want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None):
+    """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
+    `batches`).  Returns (report dict, pm.Merge or None).  keep_texts: optional dict that receives
+    {batch: post-filtered text} (tests)."""
+    from . import pgzip
+    t_start = time.perf_counter()
+    os.makedirs(out_dir, exist_ok=True)
+    nq, n_terms = queries.count()
+    nb = nb_best_hits
+    budget = budget_bytes if budget_bytes else 0.6 * pm.device_info()["hbm_free"]
+    admit = Admission(budget)
+    merge = pm.Merge(queries, keep=nb) if want_merge else None
+    ready, ready_cv, failed = [], threading.Condition(), []
+    acc = {"load_s": 0.0, "format_s": 0.0, "gzip_s": 0.0, "merge_s": 0.0, "match_only_s": 0.0, "gpu_wait_s": 0.0,
+           "d2h_s": 0.0}
+    acc_mu = threading.Lock()
+
+    def add_time(key, dt):
+        with acc_mu:
+            acc[key] += dt
+
+    def load(ticket, pos):
+        b = batches[pos]
+        need = source.need(b)
+        try:
+            admit.acquire(ticket, need)
+            t0 = time.perf_counter()
+            try:
+                ix = source.load(b)
+            except BaseException:
+                admit.release(need)
+                raise
+            held = float(ix.info.device_bytes)
+            admit.release(need - held)                  # keep only what the matrix really occupies
+            add_time("load_s", time.perf_counter() - t0)
+            item = (pos, ix, held)
+        except BaseException as e:                      # the consumer re-raises it
+            with ready_cv:
+                failed.append(e)
+                ready_cv.notify_all()
+            return
+        with ready_cv:
+            ready.append(item)
+            ready_cv.notify_all()
+
+    def take_ready(block):
+        """every batch that is resident by now (at most max_group), or [] when none is and block is False"""
+        with ready_cv:
+            while block and not ready and not failed:
+                ready_cv.wait()
+            if failed:
+                raise failed[0]
+            n = len(ready) if max_group <= 0 else min(len(ready), max_group)
+            group = sorted(ready[:n])
+            del ready[:n]
+            return group
+
+    deflaters = ThreadPoolExecutor(max_workers=max(2, min(16, len(os.sched_getaffinity(0)))))
+    workers = ThreadPoolExecutor(max_workers=max(2, min(6, len(os.sched_getaffinity(0)) // 2)))
+    group_rows = []
+
+    def finish(group, res, t_queued):
+        """host half of a group: runs while the GPU scans the next one"""
+        t0 = time.perf_counter()
+        res.wait()
+        st = res.stats
+        t1 = time.perf_counter()
+        hits = res.hits(copy=False)                     # ordered (slot, query, ...): view of pinned memory, lives as long as `res`
+        t2 = time.perf_counter()
+        cut = np.searchsorted(hits["slot"], np.arange(len(group) + 1, dtype=np.uint32))
+        add_time("gpu_wait_s", t1 - t0); add_time("d2h_s", t2 - t1); add_time("match_only_s", st.ms_total * 1e-3)
+
+        def one(i):
+            pos, ix, _held = group[i]
+            b = batches[pos]
+            part = hits[cut[i]:cut[i + 1]]
+            ta = time.perf_counter()
+            text = pm.format_hits(ix, queries, part, slot=i, nb_best_hits=nb)
+            tb = time.perf_counter()
+            # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
+            pgzip.write(os.path.join(out_dir, f"{b}____{qfile}.gz"), text, level=1, pool=deflaters)
+            tc = time.perf_counter()
+            if merge is not None:
+                merge.add(b, ix, part, slot=i, nb_best_hits=nb)
+            td = time.perf_counter()
+            add_time("format_s", tb - ta); add_time("gzip_s", tc - tb); add_time("merge_s", td - tc)
+            if keep_texts is not None:
+                keep_texts[b] = text
+            return len(part)
+        n_rec = list(workers.map(one, range(len(group))))
+        res.free()
+        for pos, ix, held in group:
+            ix.free()
+            admit.release(held)
+        group_rows.append({"batches": [batches[p] for p, _, _ in group], "scan_launches": int(st.n_scan_launches),
+                           "gpu_ms": round(st.ms_total, 3), "records": int(sum(n_rec)),
+                           "queued_to_done_s": round(time.perf_counter() - t_queued, 3)})
+
+    with ThreadPoolExecutor(max_workers=max(1, loaders)) as pool:
+        futures = [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
+        try:
+            left, pending = len(mine), None
+            while left or pending:
+                group = take_ready(block=pending is None) if left else []
+                cur = None
+                if group:
+                    for pos, ix, _ in group:
+                        info = ix.info
+                        if ix.device != pm.bound_device():
+                            raise SystemExit(f"batch {batches[pos]}: matrix is on GPU {ix.device}, this rank drives GPU {pm.bound_device()}")
+                        if info.term_size != 31:
+                            raise SystemExit(f"batch {batches[pos]}: term_size {info.term_size} != 31")
+                    tq = time.perf_counter()
+                    cur = (group, pm.search_async([ix for _, ix, _ in group], queries, threshold, nb_best_hits=max(nb, 0)), tq)
+                    left -= len(group)
+                if pending:
+                    finish(*pending)
+                pending = cur
+        except BaseException:
+            admit.abort()                    # loaders waiting for budget would wait forever otherwise
+            for f in futures:
+                f.cancel()
+            raise
+    workers.shutdown()
+    deflaters.shutdown()
+    report = {"batches": len(mine), "queries": nq, "kmers": n_terms, "groups": len(group_rows),
+              "scan_launches": sum(g["scan_launches"] for g in group_rows),
+              "match_only_s": round(acc["match_only_s"], 4), "gpu_wait_s": round(acc["gpu_wait_s"], 4),
+              "d2h_s": round(acc["d2h_s"], 4), "load_s_thread_sum": round(acc["load_s"], 3),
+              "format_s_thread_sum": round(acc["format_s"], 3), "gzip_s_thread_sum": round(acc["gzip_s"], 3),
+              "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
+              "per_group": group_rows}
+    return report, merge
+
+
+def bind_rank_to_gpu(local_rank, n_visible):
+    """one rank per GPU; several ranks may share a device only when the launcher narrowed the visible
+    devices to one per rank (HIP_VISIBLE_DEVICES) or PHYLIGN_SHARE_GPU is set (functional tests)"""
+    if local_rank < n_visible:
+        return local_rank
+    if n_visible == 1 or os.environ.get("PHYLIGN_SHARE_GPU"):
+        return local_rank % max(n_visible, 1)
+    raise SystemExit(f"local rank {local_rank} but only {n_visible} GPUs are visible: launch one rank per GPU "
+                     "(or set PHYLIGN_SHARE_GPU=1 to let ranks share devices)")
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--batches", required=True)
-    ap.add_argument("--cobs-dir", required=True)
+    ap.add_argument("--batches", default=None)
+    ap.add_argument("--cobs-dir", default=None)
     ap.add_argument("--sizes", default=None, help="data/decompressed_indexes_sizes.txt")
     ap.add_argument("--queries", required=True)
     ap.add_argument("--out-dir", required=True)
@@ -113,9 +313,14 @@ def main(argv=None):
     ap.add_argument("--filter-out", default=None)
     ap.add_argument("--loaders", type=int, default=4, help="concurrent xz decoders per rank")
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
+    ap.add_argument("--max-group", type=int, default=0, help="most batches fused into one search (0 = every resident batch)")
+    ap.add_argument("--raw-queries", action="store_true",
+                    help="--queries is an unprocessed FASTA/FASTQ (multi-line, lower case, IUPAC codes): apply rule "
+                         "fix_query (Snakefile:314-333) in the native parser instead of seqtk + awk")
+    ap.add_argument("--synthetic", default=None, metavar="WORKLOAD[:WORLD:RANK]",
+                    help="measurement aid: 661k-shaped synthetic signatures generated in HBM instead of --cobs-dir files "
+                         "(workload.select name; WORLD:RANK = hold only that shard of a WORLD-way split)")
     args = ap.parse_args(argv)
-
-    from . import _lib as pm
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,137 +330,107 @@ def main(argv=None):
         import torch
         import torch.distributed as dist
         from .dist import gather_hits
-        if os.environ.get("PHYLIGN_SHARE_GPU") or local_rank >= max(torch.cuda.device_count(), 1):
-            # functional tests (several ranks, one GPU), or a launcher that narrowed the visible devices per rank
-            local_rank %= max(torch.cuda.device_count(), 1)
-    if world > 1:
+        local_rank = bind_rank_to_gpu(local_rank, torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    from . import _lib as pm
+    from . import workload as W
     pm.init(local_rank)
-    t_start = time.time()
+    t_start = time.perf_counter()
 
-    batches = read_batches(args.batches)
-    sizes = read_sizes(args.sizes)
-    parts = lpt([sizes.get(b, 1) for b in batches], world)
+    if args.synthetic:
+        spec = args.synthetic.split(":")
+        shapes = W.select(spec[0])
+        if len(spec) == 3:                                           # one shard of an emulated split
+            shapes = [shapes[i] for i in W.assign_batches(shapes, int(spec[1]))[int(spec[2])]]
+        batches = sorted(s.batch for s in shapes)
+        source = SynthSource(pm, shapes)
+        sizes = {s.batch: s.index_bytes for s in shapes}
+    else:
+        if not args.batches or not args.cobs_dir:
+            ap.error("--batches and --cobs-dir are required (unless --synthetic)")
+        batches = read_batches(args.batches)
+        sizes = read_sizes(args.sizes)
+        source = FileSource(pm, args.cobs_dir, sizes)
+    parts = W.assign_named(batches, sizes, world)
     mine = parts[rank]
     qfile = os.path.basename(args.queries)
     qfile = qfile[:-3] if qfile.endswith(".fa") else qfile
-    os.makedirs(args.out_dir, exist_ok=True)
     with open(args.queries, "rb") as f:
         fasta = f.read()
-    queries = pm.Queries(fasta, term_size=31)          # 661k indexes are 31-mer indexes; checked per index below
-    nq, n_terms = queries.count()
+    queries = pm.Queries(fasta, term_size=31, normalise=args.raw_queries)   # 661k indexes are 31-mer indexes; checked per batch
+    budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else None
+    report, merge = run_stage(pm, batches, mine, source, queries, qfile, args.out_dir, args.threshold, args.nb_best_hits,
+                              want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
+                              max_group=args.max_group)
 
-    budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else 0.6 * pm.device_info()["hbm_free"]
-    admit = Admission(budget)
-
-    def load(ticket, pos):
-        b = batches[pos]
-        # what the loader may allocate at most: the line-aligned layout never needs more than twice
-        # the file's bytes (a 65-byte row becomes 128), plus the two 32 MiB staging chunks
-        need = 2.0 * float(sizes.get(b, 0)) + (128 << 20)
-        admit.acquire(ticket, need)
-        t0 = time.time()
-        try:
-            fobj, proc = open_index_stream(args.cobs_dir, b)
-            try:
-                ix = pm.Index.load_fd(fobj.fileno(), size_hint=sizes.get(b, 0))
-            finally:
-                fobj.close()
-                if proc is not None and proc.wait() != 0:
-                    raise RuntimeError(f"xzcat failed on batch {b}")
-        except BaseException:
-            admit.release(need)
-            raise
-        held = float(ix.info.device_bytes)
-        admit.release(need - held)                      # keep only what the matrix really occupies
-        return pos, ix, held, time.time() - t0
-
-    from . import pgzip
-    writers = ThreadPoolExecutor(max_workers=4)
-    deflaters = ThreadPoolExecutor(max_workers=max(2, min(16, len(os.sched_getaffinity(0)))))
-
-    def write_gz(path, text):
-        # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
-        pgzip.write(path, text, level=1, pool=deflaters)
-
-    kept, names_of, log_rows, pending = [], {}, [], []
-    nb = args.nb_best_hits
-
-    def consume(futures):
-        for fut in futures:
-            pos, ix, need, t_load = fut.result()
-            b = batches[pos]
-            info = ix.info
-            if ix.device != pm.bound_device():
-                raise SystemExit(f"batch {b}: matrix is on GPU {ix.device}, this rank drives GPU {pm.bound_device()}")
-            if info.term_size != 31:
-                raise SystemExit(f"batch {b}: term_size {info.term_size} != 31")
-            t0 = time.time()
-            res = pm.search([ix], queries, args.threshold, slot_base=pos, nb_best_hits=max(nb, 0))
-            hits = res.hits()
-            ms = res.stats.ms_total
-            res.free()
-            text = pm.format_hits(ix, queries, hits, slot=pos, nb_best_hits=nb)
-            pending.append(writers.submit(write_gz, os.path.join(args.out_dir, f"{b}____{qfile}.gz"), text))
-            if args.filter_out:
-                kept.append(hits)
-                names_of[pos] = ix.names()
-            ix.free()
-            admit.release(need)
-            log_rows.append({"batch": b, "load_s": round(t_load, 3), "gpu_ms": round(ms, 3), "hits": int(len(hits)),
-                             "search_and_format_s": round(time.time() - t0, 3)})
-
-    with ThreadPoolExecutor(max_workers=max(1, args.loaders)) as pool:
-        futures = [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
-        try:
-            consume(futures)
-        except BaseException:
-            admit.abort()                    # loaders waiting for budget would wait forever otherwise
-            for f in futures:
-                f.cancel()
-            raise
-    for p in pending:
-        p.result()
-    writers.shutdown()
-    deflaters.shutdown()
-
-    # ---- 04_filter: gather the pruned records (and names) to rank 0, merge natively
+    # ---- 04_filter: one gather of what every rank's merge kept, rank 0 adds the parts and emits
+    t_f = time.perf_counter()
     if args.filter_out:
-        local = np.concatenate(kept) if kept else np.zeros(0, dtype=pm.HIT_DTYPE)
-        all_names = [names_of]
-        allhits = local
         if world > 1:
-            t = torch.from_numpy(local.view(np.int32).reshape(-1, 4).copy())
+            ex = merge.export()
+            mine_names = [(batches[p], None) for p in mine]          # add() order = ordinal in the export's slot field
+            order = report["merge_order"] = [b for g in report["per_group"] for b in g["batches"]]
+            t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
             if backend == "nccl":
                 t = t.cuda()
             g = gather_hits(t, dst=0)
-            all_names = [None] * world if rank == 0 else None
-            dist.gather_object(names_of, all_names, dst=0)
+            counts = [None] * world if rank == 0 else None
+            dist.gather_object((len(ex), order), counts, dst=0)
             if rank == 0:
-                allhits = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+                allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+                off = 0
+                for r, (n, r_order) in enumerate(counts):
+                    part = allrec[off:off + n]
+                    off += n
+                    if r == 0:
+                        continue                                      # rank 0's own matches are in `merge` already
+                    cut = np.searchsorted(part["slot"], np.arange(len(r_order) + 1, dtype=np.uint32))
+                    for k, b in enumerate(r_order):
+                        if cut[k + 1] > cut[k]:
+                            nix = names_index(pm, source, b)
+                            merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1)
+                            nix.free()
+            del mine_names
         if rank == 0:
-            names = {}
-            for d in all_names:
-                names.update(d)
-            m = pm.Merge(queries, keep=args.nb_best_hits)
-            for pos in sorted(names):                        # file order of the consumer = sorted batches
-                ix = pm.Index.from_names(names[pos])
-                m.add(batches[pos], ix, allhits[allhits["slot"] == pos], slot=pos, nb_best_hits=nb)
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
             tmp = args.filter_out + ".tmp"
             with open(tmp, "wb") as f:
-                f.write(m.emit())
+                f.write(merge.emit())
             os.replace(tmp, args.filter_out)
+    report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    print(json.dumps({"rank": rank, "world": world, "batches": len(mine), "queries": nq, "kmers": n_terms,
-                      "wall_s": round(time.time() - t_start, 3), "per_batch": log_rows}), file=sys.stderr)
+    report.update({"rank": rank, "world": world, "e2e_s": round(time.perf_counter() - t_start, 3)})
+    print(json.dumps(report), file=sys.stderr)
+
+
+def names_index(pm, source, batch):
+    """names-only handle of a batch this rank did not search (rank 0 turning gathered records into references)"""
+    if isinstance(source, SynthSource):
+        s = source.by_name[batch]
+        return pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, source.seed, header_only=True)
+    fobj, proc = open_index_stream(source.cobs_dir, batch)
+    try:
+        head = bytearray()
+        while True:                                                   # the header ends with the closing magic: read until it parses
+            chunk = fobj.read(1 << 20)
+            head += chunk
+            try:
+                return pm.Index.load_header_mem(bytes(head))
+            except pm.PMError:
+                if not chunk:
+                    raise
+    finally:
+        fobj.close()
+        if proc is not None:
+            proc.kill()
+            proc.wait()
 
 
 if __name__ == "__main__":

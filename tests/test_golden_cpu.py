@@ -308,6 +308,51 @@ def test_native_merge_matches_reference_filter_fixture(keep):
     assert m.emit().decode() == open(os.path.join(d, f"expected.n{keep}.fa")).read()
 
 
+def _filter_fixture_batches(pm):
+    import gzip
+    d = os.path.join(GOLD, "filter")
+    order = {}
+    for i, line in enumerate(l for l in open(os.path.join(d, "queries.fa")) if l.startswith(">")):
+        order[line[1:].split()[0]] = i
+    out = []
+    for b in ("aaa_bbb__01", "ccc_ddd__01", "ccc_ddd__02"):
+        names, recs, qi = {}, [], None
+        for line in gzip.open(os.path.join(d, f"{b}____q.gz"), "rt"):
+            if line.startswith("*"):
+                qi = order[line[1:].split("\t")[0].split(" ")[0]]
+            else:
+                name, score = line.split()
+                recs.append((qi, names.setdefault(name, len(names)), int(score), 0))
+        out.append((b, list(names) or ["x_y"], np.array(recs, dtype=pm.HIT_DTYPE)))
+    return out
+
+
+@pytest.mark.parametrize("keep", [1, 2, 5, 100])
+@pytest.mark.parametrize("split", [(0,), (0, 1), (2,), (1, 2)])
+def test_native_merge_export_of_parts_equals_one_merge(keep, split):
+    """pm_merge_export: two ranks merge their own batches, rank 0 adds both exports again -- the 04_filter
+    FASTA equals the reference's (the multi-GPU form of match_stage), in any order of the parts."""
+    from phylign_amd import _lib as pm
+    d = os.path.join(GOLD, "filter")
+    q = pm.Queries(open(os.path.join(d, "queries.fa"), "rb").read(), term_size=31)
+    batches = _filter_fixture_batches(pm)
+    parts = [[i for i in range(3) if i in split], [i for i in range(3) if i not in split]]
+    root = pm.Merge(q, keep)
+    for part in reversed(parts):                         # rank order must not matter
+        m = pm.Merge(q, keep)
+        for i in part:
+            b, names, recs = batches[i]
+            ix = pm.Index.from_names(names)
+            m.add(b, ix, recs, slot=0, nb_best_hits=-1)
+            ix.free()                                    # the merge keeps its own copy of the names
+        ex = m.export()
+        assert np.array_equal(ex, pm.sort_hits(ex.copy()))
+        for k, i in enumerate(part):
+            b, names, _ = batches[i]
+            root.add(b, pm.Index.from_names(names), ex[ex["slot"] == k], slot=k, nb_best_hits=-1)
+    assert root.emit().decode() == open(os.path.join(d, f"expected.n{keep}.fa")).read()
+
+
 # ------------------------------------------------------ fix_query mirror (f4)
 def test_fix_query_rules_and_awk_fixed_point(tmp_path):
     from phylign_amd import fix_query as FQ

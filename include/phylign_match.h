@@ -179,6 +179,15 @@ void pm_index_free(pm_index_t* idx);
  * are dropped.  Fails with PM_EQUERY on a sequence shorter than term_size or
  * holding a byte outside ACGT. */
 int  pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out);
+/* normalise != 0: `buf` is an unprocessed query file (FASTA or FASTQ, multi-line, lower case, IUPAC
+ * codes, comments) and the parser applies rules fix_query + concatenate_queries itself
+ * (Snakefile:314-352: `seqtk seq -A -U -C | awk gsub(/[^ACGT]/, "A")`, kseq record rules): names cut
+ * at the first blank, sequences joined, upper-cased, every byte outside ACGT mapped to 'A', quality
+ * dropped.  normalise == 0 is pm_queries_parse. */
+int  pm_queries_parse_raw(const char* buf, size_t len, uint32_t term_size, int normalise, pm_queries_t** out);
+/* the prepared single-line FASTA this query set stands for (what intermediate/01_queries_merged/
+ * holds in the reference); *text malloc'd, pm_free() */
+int  pm_queries_fasta(const pm_queries_t* q, char** text, size_t* len);
 int  pm_queries_count(const pm_queries_t* q, uint64_t* n_queries, uint64_t* n_terms);
 /* number of k-mers of record i (length - k + 1) */
 int  pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_terms);

@@ -76,6 +76,8 @@ SYMBOLS = [
     ("pm_index_read_row", C.c_int, [_P, C.c_uint64, _P]),
     ("pm_index_free", None, [_P]),
     ("pm_queries_parse", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    ("pm_queries_parse_raw", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    ("pm_queries_fasta", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_queries_count", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pm_queries_terms", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("pm_queries_free", None, [_P]),
@@ -275,10 +277,20 @@ class Index:
 class Queries:
     """A query FASTA parsed with the cobs CLI's record rules, resident in HBM."""
 
-    def __init__(self, fasta: bytes, term_size=31):
+    def __init__(self, fasta: bytes, term_size=31, normalise=False):
+        """normalise: `fasta` is an unprocessed FASTA/FASTQ; rules fix_query + concatenate_queries
+        (Snakefile:314-352) are applied by the native parser"""
         h = _P()
-        _chk(load().pm_queries_parse(fasta, len(fasta), term_size, C.byref(h)))
+        _chk(load().pm_queries_parse_raw(fasta, len(fasta), term_size, int(bool(normalise)), C.byref(h)))
         self._h = h
+
+    def fasta(self) -> bytes:
+        """the prepared single-line FASTA this set stands for"""
+        t, n = _P(), C.c_size_t()
+        _chk(load().pm_queries_fasta(self._h, C.byref(t), C.byref(n)))
+        out = C.string_at(t.value, n.value)
+        load().pm_free(t)
+        return out
 
     def count(self):
         nq, nt = C.c_uint64(), C.c_uint64()

@@ -6,67 +6,43 @@
 // Record rules of `cobs query -f` (upstream src/main.cpp process_query): see
 // include/phylign_match.h.  The input contract (upper-case ACGT, single line)
 // is produced by Snakefile:314-333.
-extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
-    if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
-    pm_queries* q = new pm_queries();
-    q->k = term_size;
-    std::string& seqs = q->seqs;            // packed sequences
-    std::vector<uint64_t>& seq_off = q->seq_off;
-    std::string cur_hdr, cur_seq;
-    bool have_any = false;
-    int rc = PM_OK;
-    auto flush = [&]() -> int {
-        if (cur_seq.empty()) return PM_OK;
-        if (cur_seq.size() < term_size)
-            return fail(PM_EQUERY, "query '%s' too short: %zu < %u characters", cur_hdr.c_str(), cur_seq.size(), term_size);
-        for (size_t i = 0; i < cur_seq.size(); ++i) {
-            const char c = cur_seq[i];
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T')
-                return fail(PM_EQUERY, "query '%s': byte 0x%02x at position %zu is not one of ACGT "
-                            "(Phylign's fix_query step maps such bases to A)", cur_hdr.c_str(), (unsigned char)c, i);
-        }
-        const uint64_t nt = cur_seq.size() - term_size + 1;
-        if (nt >= (1ull << 24)) return fail(PM_ERANGE, "query '%s' has %llu k-mers; this build supports < 2^24 per query",
-                                            cur_hdr.c_str(), (unsigned long long)nt);
-        q->headers.push_back(cur_hdr);
-        q->headerless.push_back(have_any ? 0 : 1);
-        q->n_terms.push_back((uint32_t)nt);
-        seq_off.push_back(seqs.size());
-        seqs += cur_seq;
-        return PM_OK;
-    };
-    size_t p = 0;
-    while (p < len && rc == PM_OK) {
-        const char* nl = (const char*)memchr(fasta + p, '\n', len - p);
-        size_t ll = nl ? (size_t)(nl - (fasta + p)) : len - p;
-        const char* line = fasta + p;
-        p += ll + (nl ? 1 : 0);
-        if (ll == 0) continue;
-        if (line[0] == '>' || line[0] == ';') {
-            rc = flush();
-            cur_hdr.assign(line + 1, ll - 1);
-            cur_seq.clear();
-            have_any = true;
-        } else {
-            cur_seq.append(line, ll);
-        }
+// appends one record; PM_EQUERY / PM_ERANGE as documented in the header
+static int add_record(pm_queries* q, const std::string& hdr, const std::string& seq, bool headerless) {
+    const uint32_t term_size = q->k;
+    if (seq.size() < term_size)
+        return fail(PM_EQUERY, "query '%s' too short: %zu < %u characters", hdr.c_str(), seq.size(), term_size);
+    for (size_t i = 0; i < seq.size(); ++i) {
+        const char c = seq[i];
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T')
+            return fail(PM_EQUERY, "query '%s': byte 0x%02x at position %zu is not one of ACGT "
+                        "(Phylign's fix_query step maps such bases to A: pm_queries_parse_raw(normalise = 1))", hdr.c_str(), (unsigned char)c, i);
     }
-    if (rc == PM_OK) rc = flush();
-    if (rc != PM_OK) { delete q; return rc; }
+    const uint64_t nt = seq.size() - term_size + 1;
+    if (nt >= (1ull << 24)) return fail(PM_ERANGE, "query '%s' has %llu k-mers; this build supports < 2^24 per query",
+                                        hdr.c_str(), (unsigned long long)nt);
+    q->headers.push_back(hdr);
+    q->headerless.push_back(headerless ? 1 : 0);
+    q->n_terms.push_back((uint32_t)nt);
+    q->seq_off.push_back(q->seqs.size());
+    q->seqs += seq;
+    return PM_OK;
+}
 
+// descriptors, 8-slot blocks and counter-width classes of the records added so far
+static int finish_queries(pm_queries* q) {
     const size_t nq = q->headers.size();
-    seq_off.push_back(seqs.size());
-    if (nq >= 0xFFFFFFFFull) { delete q; return fail(PM_ERANGE, "too many queries"); }
+    q->seq_off.push_back(q->seqs.size());
+    if (nq >= 0xFFFFFFFFull) return fail(PM_ERANGE, "too many queries");
     q->qd.resize(nq);
     uint64_t blk = 0;
     for (size_t i = 0; i < nq; ++i) {
         q->qd[i].n_terms = q->n_terms[i];
         q->qd[i].pad_blk = (uint32_t)blk;
-        q->qd[i].seq_lo = (uint32_t)seq_off[i];
-        q->qd[i].seq_hi = (uint32_t)(seq_off[i] >> 32);
+        q->qd[i].seq_lo = (uint32_t)q->seq_off[i];
+        q->qd[i].seq_hi = (uint32_t)(q->seq_off[i] >> 32);
         blk += (q->n_terms[i] + 7) / 8;
         q->total_terms += q->n_terms[i];
-        if (blk >= 0xFFFFFFFFull) { delete q; return fail(PM_ERANGE, "query set too large (>= 2^35 padded k-mers)"); }
+        if (blk >= 0xFFFFFFFFull) return fail(PM_ERANGE, "query set too large (>= 2^35 padded k-mers)");
     }
     q->n_slots = blk * 8;
     std::vector<uint32_t> blkq((size_t)blk);
@@ -85,11 +61,142 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
         for (size_t i = 0; i < nq; ++i) if (cls(q->n_terms[i]) == c) q->qmap.push_back((uint32_t)i);
     }
     q->class_begin[kNumClasses] = (uint32_t)q->qmap.size();
-
     q->blkq.swap(blkq);
     // HBM copies are made on first use by a compute call (upload_queries): parsing, text
     // formatting and the 04_filter merge are host work and need no GPU
+    return PM_OK;
+}
+
+extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
+    if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
+    pm_queries* q = new pm_queries();
+    q->k = term_size;
+    std::string cur_hdr, cur_seq;
+    bool have_any = false;
+    int rc = PM_OK;
+    auto flush = [&]() -> int {
+        if (cur_seq.empty()) return PM_OK;
+        return add_record(q, cur_hdr, cur_seq, !have_any);
+    };
+    size_t p = 0;
+    while (p < len && rc == PM_OK) {
+        const char* nl = (const char*)memchr(fasta + p, '\n', len - p);
+        size_t ll = nl ? (size_t)(nl - (fasta + p)) : len - p;
+        const char* line = fasta + p;
+        p += ll + (nl ? 1 : 0);
+        if (ll == 0) continue;
+        if (line[0] == '>' || line[0] == ';') {
+            rc = flush();
+            cur_hdr.assign(line + 1, ll - 1);
+            cur_seq.clear();
+            have_any = true;
+        } else {
+            cur_seq.append(line, ll);
+        }
+    }
+    if (rc == PM_OK) rc = flush();
+    if (rc == PM_OK) rc = finish_queries(q);
+    if (rc != PM_OK) { delete q; return rc; }
     *out = q;
+    return PM_OK;
+}
+
+// Rules `fix_query` + `concatenate_queries` (Snakefile:314-352) fused into the parser: what
+//   seqtk seq -A -U -C in | awk '{if(NR%2==1){print $0;}else{gsub(/[^ACGT]/, "A"); print;}}'
+// writes, read with kseq's record rules (seqtk's reader):
+//   * bytes before the first line that starts with '>' or '@' are skipped;
+//   * name = the header up to its first blank (space, TAB) -- the comment is dropped (-C);
+//   * sequence = the following lines concatenated, up to a line that starts with '>', '@' or '+';
+//     empty lines are skipped, a trailing '\r' is dropped;
+//   * '+' starts a FASTQ quality block: the rest of that line is skipped, then quality lines are
+//     read until they hold at least as many characters as the sequence (so '@' or '>' as a quality
+//     value never starts a record); a block that ends early or runs long ends the input there,
+//     like seqtk's read loop (the broken record is not printed);
+//   * -U upper-cases, awk maps every byte that is not A, C, G or T to 'A';
+//   * a record without sequence is printed by seqtk as an empty line and ignored by cobs: dropped.
+// A sequence shorter than term_size stays an error (PM_EQUERY), exactly as for a prepared file.
+static int parse_raw_normalised(pm_queries* q, const char* buf, size_t len) {
+    size_t p = 0;
+    auto next_line = [&](const char** line, size_t* ll) -> bool {        // false at end of input
+        if (p >= len) return false;
+        const char* nl = (const char*)memchr(buf + p, '\n', len - p);
+        size_t l = nl ? (size_t)(nl - (buf + p)) : len - p;
+        *line = buf + p;
+        p += l + (nl ? 1 : 0);
+        if (l && (*line)[l - 1] == '\r') --l;
+        *ll = l;
+        return true;
+    };
+    const char* line = nullptr; size_t ll = 0;
+    bool have = next_line(&line, &ll);
+    while (have && !(ll && (line[0] == '>' || line[0] == '@'))) have = next_line(&line, &ll);
+    std::string name, seq;
+    while (have) {
+        // `line` is a header line
+        size_t e = 1;
+        while (e < ll && line[e] != ' ' && line[e] != '\t') ++e;
+        name.assign(line + 1, e - 1);
+        seq.clear();
+        have = next_line(&line, &ll);
+        while (have && !(ll && (line[0] == '>' || line[0] == '@' || line[0] == '+'))) {
+            seq.append(line, ll);
+            have = next_line(&line, &ll);
+        }
+        bool stop = false;
+        if (have && line[0] == '+') {
+            size_t qual = 0;
+            have = next_line(&line, &ll);
+            while (have) {
+                qual += ll;
+                if (qual >= seq.size()) break;
+                have = next_line(&line, &ll);
+            }
+            if (qual != seq.size()) stop = true;          // truncated or overlong quality: kseq_read returns -2
+            else {
+                have = next_line(&line, &ll);
+                while (have && !(ll && (line[0] == '>' || line[0] == '@'))) have = next_line(&line, &ll);
+            }
+        }
+        if (stop) break;
+        for (char& c : seq) {
+            if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') c = 'A';
+        }
+        if (!seq.empty()) { int rc = add_record(q, name, seq, false); if (rc) return rc; }
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_queries_parse_raw(const char* buf, size_t len, uint32_t term_size, int normalise, pm_queries_t** out) {
+    if (!normalise) return pm_queries_parse(buf, len, term_size, out);
+    if ((!buf && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
+    pm_queries* q = new pm_queries();
+    q->k = term_size;
+    int rc = parse_raw_normalised(q, buf, len);
+    if (rc == PM_OK) rc = finish_queries(q);
+    if (rc != PM_OK) { delete q; return rc; }
+    *out = q;
+    return PM_OK;
+}
+
+// ">header\nSEQUENCE\n" per record: the prepared query file (intermediate/01_queries_merged/*.fa) this set stands for
+extern "C" int pm_queries_fasta(const pm_queries_t* q, char** text, size_t* len) {
+    if (!q || !text || !len) return fail(PM_EINVAL, "bad argument");
+    size_t total = 0;
+    for (size_t i = 0; i < q->headers.size(); ++i) total += q->headers[i].size() + 3 + (size_t)(q->seq_off[i + 1] - q->seq_off[i]);
+    char* buf = (char*)malloc(total + 1);
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    size_t o = 0;
+    for (size_t i = 0; i < q->headers.size(); ++i) {
+        if (!q->headerless[i]) buf[o++] = '>';
+        memcpy(buf + o, q->headers[i].data(), q->headers[i].size()); o += q->headers[i].size();
+        buf[o++] = '\n';
+        const size_t sl = (size_t)(q->seq_off[i + 1] - q->seq_off[i]);
+        memcpy(buf + o, q->seqs.data() + q->seq_off[i], sl); o += sl;
+        buf[o++] = '\n';
+    }
+    buf[o] = 0;
+    *text = buf; *len = o;
     return PM_OK;
 }
 

@@ -154,6 +154,21 @@ class SynthSource:
         return ix
 
 
+class ResidentSource:
+    """indexes that are in HBM already (a resident-index server, a measurement that keeps load time out
+    of the timed region): the stage searches them as ONE group; they are not freed by the stage"""
+    resident = True
+
+    def __init__(self, indexes):
+        self.indexes = dict(indexes)                   # batch name -> pm.Index
+
+    def need(self, batch):
+        return 0.0
+
+    def load(self, batch):
+        return self.indexes[batch]
+
+
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
               want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
@@ -170,7 +185,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     ready, ready_cv, failed = [], threading.Condition(), []
     acc = {"load_s": 0.0, "format_s": 0.0, "gzip_s": 0.0, "merge_s": 0.0, "match_only_s": 0.0, "gpu_wait_s": 0.0,
            "d2h_s": 0.0}
-    acc_mu = threading.Lock()
+    acc_mu, merge_mu, merge_order = threading.Lock(), threading.Lock(), []
 
     def add_time(key, dt):
         with acc_mu:
@@ -238,7 +253,9 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             pgzip.write(os.path.join(out_dir, f"{b}____{qfile}.gz"), text, level=1, pool=deflaters)
             tc = time.perf_counter()
             if merge is not None:
-                merge.add(b, ix, part, slot=i, nb_best_hits=nb)
+                with merge_mu:                           # the library serialises adds anyway; the ordinal of the add is the export's slot
+                    merge.add(b, ix, part, slot=i, nb_best_hits=nb)
+                    merge_order.append(b)
             td = time.perf_counter()
             add_time("format_s", tb - ta); add_time("gzip_s", tc - tb); add_time("merge_s", td - tc)
             if keep_texts is not None:
@@ -247,14 +264,18 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
         n_rec = list(workers.map(one, range(len(group))))
         res.free()
         for pos, ix, held in group:
-            ix.free()
+            if not resident:
+                ix.free()
             admit.release(held)
         group_rows.append({"batches": [batches[p] for p, _, _ in group], "scan_launches": int(st.n_scan_launches),
                            "gpu_ms": round(st.ms_total, 3), "records": int(sum(n_rec)),
                            "queued_to_done_s": round(time.perf_counter() - t_queued, 3)})
 
+    resident = bool(getattr(source, "resident", False))
+    if resident:                                        # nothing to decode: every batch is ready, no loader threads
+        ready.extend((pos, source.load(batches[pos]), 0.0) for pos in mine)
     with ThreadPoolExecutor(max_workers=max(1, loaders)) as pool:
-        futures = [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
+        futures = [] if resident else [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
         try:
             left, pending = len(mine), None
             while left or pending:
@@ -286,7 +307,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
               "d2h_s": round(acc["d2h_s"], 4), "load_s_thread_sum": round(acc["load_s"], 3),
               "format_s_thread_sum": round(acc["format_s"], 3), "gzip_s_thread_sum": round(acc["gzip_s"], 3),
               "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
-              "per_group": group_rows}
+              "per_group": group_rows, "merge_order": merge_order}
     return report, merge
 
 
@@ -372,19 +393,17 @@ def main(argv=None):
     t_f = time.perf_counter()
     if args.filter_out:
         if world > 1:
-            ex = merge.export()
-            mine_names = [(batches[p], None) for p in mine]          # add() order = ordinal in the export's slot field
-            order = report["merge_order"] = [b for g in report["per_group"] for b in g["batches"]]
+            ex = merge.export()                                      # slot = ordinal of the add = position in merge_order
             t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
             if backend == "nccl":
                 t = t.cuda()
             g = gather_hits(t, dst=0)
-            counts = [None] * world if rank == 0 else None
-            dist.gather_object((len(ex), order), counts, dst=0)
+            meta = [None] * world if rank == 0 else None
+            dist.gather_object((len(ex), report["merge_order"]), meta, dst=0)
             if rank == 0:
                 allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
                 off = 0
-                for r, (n, r_order) in enumerate(counts):
+                for r, (n, r_order) in enumerate(meta):
                     part = allrec[off:off + n]
                     off += n
                     if r == 0:
@@ -395,7 +414,6 @@ def main(argv=None):
                             nix = names_index(pm, source, b)
                             merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1)
                             nix.free()
-            del mine_names
         if rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
             tmp = args.filter_out + ".tmp"

@@ -83,6 +83,24 @@ def assign_batches(shapes, n_ranks, capacity_bytes=None):
     return [sorted(x) for x in out]
 
 
+def assign_named(batches, sizes, n_ranks, capacity_bytes=None):
+    """assign_batches for a real batch list (match_stage): `batches` are names, `sizes` maps a name to
+    its decompressed index bytes (data/decompressed_indexes_sizes.txt).  A batch of the 661k collection
+    takes its document count -- hence its scan cost -- from the shape table; an unknown batch is priced
+    by the row width its size implies at the collection's typical 12.8 M rows."""
+    table = {s.batch: s for s in load_shapes()}
+    shapes = []
+    for i, b in enumerate(batches):
+        nbytes = int(sizes.get(b, 0))
+        if b in table:
+            s = table[b]
+            shapes.append(s._replace(index_bytes=nbytes or s.index_bytes, batch_id=i))
+        else:
+            rb = max(1, nbytes // 12_800_000)
+            shapes.append(Shape(b, rb * 8, max(nbytes, 1), rb, max(1, nbytes // rb), False, False, i))
+    return assign_batches(shapes, n_ranks, capacity_bytes)
+
+
 def make_queries(n, length=150, seed=31):
     """uniform ACGT queries; returns (fasta bytes, uint8 array [n, length])"""
     rng = np.random.default_rng(seed)

@@ -595,3 +595,85 @@ def test_server_routing_is_stable_and_spreads_the_661k_batches():
         load[a] = load.get(a, 0) + s.index_bytes * 1.1            # line-aligned rows cost a few percent more
     assert len(load) == 8 and max(load.values()) < 0.85 * 288e9, {k: round(v / 1e9) for k, v in load.items()}
     assert pick_server("/tmp/one.sock", "x.xz") == "/tmp/one.sock"
+
+
+# --------------------------------------- fix_query fused into the native parser (f4, pm_queries_parse_raw)
+# Hand-derived from the documented behaviour of `seqtk seq -A -U -C` (kseq record rules) followed by the
+# awk substitution of Snakefile:330-332; seqtk itself is not in the build container.
+RAW_CASES = [
+    # multi-line FASTA, lower case, IUPAC codes, comment after the name, blank line inside the sequence
+    (b">r1 some comment here\nacgtnnry\n\nACGTACGT\nacgtacgtacgtacgtacgt\n",
+     b">r1\nACGTAAAAACGTACGTACGTACGTACGTACGTACGT\n"),
+    # name cut at a TAB as well; CRLF line ends
+    (b">r2\tx y\r\nACGTACGTACGTACGTACGTACGTACGTACGTAC\r\n",
+     b">r2\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n"),
+    # FASTQ: quality dropped, '@' and '>' as first quality characters do not start records
+    (b"@q1 c\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n+\n@IIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"
+     b"@q2\nGGGGACGTACGTACGTACGTACGTACGTACGTAC\n+q2\n>IIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n",
+     b">q1\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n>q2\nGGGGACGTACGTACGTACGTACGTACGTACGTAC\n"),
+    # multi-line FASTQ sequence and quality
+    (b"@m\nACGTACGTACGTACGTAC\nGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\nIIIIIIIIIIIIIIII\n>n\nTTTTACGTACGTACGTACGTACGTACGTACGTAC\n",
+     b">m\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n>n\nTTTTACGTACGTACGTACGTACGTACGTACGTAC\n"),
+    # junk before the first header is skipped; a record without sequence disappears (cobs ignores the empty line)
+    (b"junk line\n\n>empty\n>full z\nUUUUACGTACGTACGTACGTACGTACGTACGTAC\n",
+     b">full\nAAAAACGTACGTACGTACGTACGTACGTACGTAC\n"),
+    # digits, '-', '*', '.' and blanks inside a sequence line all become A (awk: every byte outside ACGT)
+    (b">g\nAC-GT*N.1 ACGTACGTACGTACGTACGTACGTAC\n", b">g\nACAGTAAAAAACGTACGTACGTACGTACGTACGTAC\n"),
+    # truncated quality block: seqtk's read loop ends there, the records before it survive
+    (b">a\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n@b\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n+\nIII\n",
+     b">a\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n"),
+    # no trailing newline
+    (b">z\nacgtacgtacgtacgtacgtacgtacgtacgtac", b">z\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(RAW_CASES)))
+def test_native_fix_query_rules(case):
+    from phylign_amd import _lib as pm
+    raw, want = RAW_CASES[case]
+    q = pm.Queries(raw, term_size=31, normalise=True)
+    assert q.fasta() == want
+    # the prepared file parses to the same set without normalisation, and is a fixed point of the rule
+    q2 = pm.Queries(want, term_size=31)
+    assert q2.fasta() == want and q2.count() == q.count()
+    assert pm.Queries(want, term_size=31, normalise=True).fasta() == want
+
+
+def test_native_fix_query_agrees_with_the_python_mirror_and_awk(tmp_path):
+    """same records as phylign_amd/fix_query.py (the Python mirror) on a random mixed file, and the awk half
+    of the reference rule leaves the native output unchanged"""
+    from phylign_amd import _lib as pm
+    from phylign_amd import fix_query as FQ
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGTacgtNnRYKMSWryu", dtype=np.uint8)
+    parts = []
+    for i in range(300):
+        n = int(rng.integers(31, 400))
+        seq = alpha[rng.integers(0, len(alpha), size=n)].tobytes()
+        width = int(rng.integers(20, 90))
+        lines = b"\n".join(seq[j:j + width] for j in range(0, n, width))
+        if i % 3 == 0:
+            qual = bytes(rng.integers(33, 74, size=n).astype(np.uint8))
+            qlines = b"\n".join(qual[j:j + width] for j in range(0, n, width))
+            parts.append(b"@rec%d comment %d\n" % (i, i) + lines + b"\n+\n" + qlines + b"\n")
+        else:
+            parts.append(b">rec%d\tdesc\n" % i + lines + b"\n")
+    raw = b"".join(parts)
+    got = pm.Queries(raw, term_size=31, normalise=True).fasta()
+    out = io.BytesIO()
+    FQ.fix_stream(io.BytesIO(raw), out)
+    assert got == out.getvalue()
+    p = tmp_path / "x.fa"
+    p.write_bytes(got)
+    r = subprocess.run(["awk", '{if(NR%2==1){print $0;}else{gsub(/[^ACGT]/, "A"); print;}}', str(p)], capture_output=True)
+    assert r.returncode == 0 and r.stdout == got
+    # the reference's bundled reads, already prepared: unchanged
+    merged = open(os.path.join(GOLD, "reads", "reads_1___reads_2___reads_3___reads_4.fa"), "rb").read()
+    assert pm.Queries(merged, term_size=31, normalise=True).fasta() == merged
+
+
+def test_unprepared_queries_are_rejected_without_normalise():
+    from phylign_amd import _lib as pm
+    with pytest.raises(pm.PMError) as e:
+        pm.Queries(b">r\nacgtacgtacgtacgtacgtacgtacgtacgtacgt\n", term_size=31)
+    assert e.value.code == -6

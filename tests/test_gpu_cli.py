@@ -189,6 +189,60 @@ def test_match_stage_end_to_end_single_rank(pm, oracle, tmp_path, n):
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, n)
 
 
+def test_match_stage_searches_resident_batches_with_fused_launches(pm, oracle, tmp_path):
+    """the stage runs the path bench.py measures: every resident batch of a group goes into ONE
+    pm_search_async, so a group costs one scan launch per (row-width class, counter-width class),
+    not one per batch (the reference: 305 separate `cobs query` jobs, Snakefile:431-487) -- and the
+    files and the 04_filter FASTA stay byte-identical"""
+    import json
+    from phylign_amd import match_stage as MS
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    batches = sorted(names)
+    src = MS.ResidentSource({b: pm.Index.load_mem(indexes[b]) for b in batches})
+    q = pm.Queries(fasta)
+    report, merge = MS.run_stage(pm, batches, list(range(len(batches))), src, q, "Q", str(tmp_path / "03_match"),
+                                 0.7, 3, want_merge=True)
+    assert report["groups"] == 1 and report["per_group"][0]["batches"] == batches
+    # 5 batches: four narrow ones share the mixed-width launch, the 4000-document one has its own
+    assert report["scan_launches"] == 2 < len(batches)
+    assert sorted(report["merge_order"]) == batches
+    (tmp_path / "04_filter").mkdir()
+    (tmp_path / "04_filter" / "Q.fa").write_bytes(merge.emit())
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    for k in ("match_only_s", "format_s_thread_sum", "gzip_s_thread_sum", "merge_s_thread_sum", "stage_wall_s"):
+        assert report[k] >= 0
+    # groups of at most two batches: three groups, still one or two launches each, same bytes
+    for f in (tmp_path / "03_match").glob("*.gz"):
+        f.unlink()
+    report2, merge2 = MS.run_stage(pm, batches, list(range(len(batches))), src, q, "Q", str(tmp_path / "03_match"),
+                                   0.7, 3, want_merge=True, max_group=2)
+    assert report2["groups"] == 3 and all(g["scan_launches"] <= 2 for g in report2["per_group"])
+    (tmp_path / "04_filter" / "Q.fa").write_bytes(merge2.emit())
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    json.dumps(report2)
+
+
+def test_match_stage_takes_unprepared_queries(pm, oracle, tmp_path):
+    """--raw-queries: rule fix_query (Snakefile:314-333) runs inside the native parser; same outputs as
+    for the prepared file"""
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path, n_batches=2)
+    recs = fasta.decode().strip().split("\n")
+    raw = "".join(f"{h} extra words\n{s[:70].lower()}\n{s[70:]}\n" for h, s in zip(recs[0::2], recs[1::2]))
+    (tmp_path / "raw.fa").write_text(raw)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+                        "--cobs-dir", str(tmp_path / "cobs"), "--sizes", str(tmp_path / "sizes.txt"),
+                        "--queries", str(tmp_path / "raw.fa"), "--raw-queries", "--out-dir", str(tmp_path / "03_match"),
+                        "--nb-best-hits", "3"], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    from phylign_amd import postprocess as P
+    # header comments are dropped by the rule (-C), so the prepared file has bare names
+    prepared = "".join(f"{h.split(' ')[0]}\n{s}\n" for h, s in zip(recs[0::2], recs[1::2])).encode()
+    for b in names:
+        exp = P.filter_text(oracle.query_file(indexes[b], prepared, 0.7).decode(), 3)
+        assert gzip.open(tmp_path / "03_match" / f"{b}____raw.gz", "rt").read() == exp, b
+
+
 def test_match_stage_fails_fast_on_a_broken_index(pm, oracle, tmp_path):
     """a truncated index stream in the middle of the batch list, loaders queued behind a tiny HBM
     budget: the stage exits non-zero promptly (waiting loaders are told to give up) and leaves no

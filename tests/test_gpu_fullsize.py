@@ -221,3 +221,133 @@ def test_config5_one_million_queries_on_one_rank_shard(pm, oracle):
     # text of one batch at this size: every query gets its header line
     text = pm.format_hits(ixs[0], q, hits, slot=0, nb_best_hits=100)
     assert text.count(b"*q") == nq
+
+
+def _query_blocks(text):
+    """{query name: [lines]} of a cobs / post-filtered text"""
+    out, cur = {}, None
+    for line in text.split("\n"):
+        if line.startswith("*"):
+            cur = out.setdefault(line[1:].split("\t")[0], [line])
+        elif line and cur is not None:
+            cur.append(line)
+    return out
+
+
+def test_configs4_5_one_rank_shard_of_the_full_collection(pm, oracle, tmp_path):
+    """BASELINE configs[3] and [4] on their own workload: the shard ONE rank holds when all 305 batches of
+    batches_full.txt are split over 8 GPUs (38 batches, ~135 GB of signatures, every row-width class of the
+    collection), driven the way the stage drives it.
+
+    configs[3] (100 k queries): sampled exact parity against the oracle on the virtual matrix for every
+    batch of the shard, exact algorithmic bytes, planted totals, sharding invariance (two halves = whole).
+    configs[4] (1 M queries, 03_match -> 04_filter): match_stage.run_stage over the resident shard writes
+    the 38 `.gz` files and the 04_filter FASTA; sampled queries are compared line by line with what the
+    oracle + the golden-pinned post-filter / filter rules give; every query has its header in every file."""
+    import gzip
+    from phylign_amd import match_stage as MS
+    from phylign_amd import postprocess as P
+    full = W.select("full")
+    assert len(full) == 305 and sum(s.row_bytes for s in full) == 82741          # SURVEY.md 8d: bytes per k-mer
+    parts = W.assign_batches(full, 8)
+    assert sorted(i for p in parts for i in p) == list(range(305))
+    mine = parts[2]
+    sub = [full[p] for p in mine]
+    assert len(sub) == 38 and 120e9 < sum(s.index_bytes for s in sub) < 145e9
+    assert {(s.row_bytes + 127) // 128 for s in sub} >= {1, 2, 4}                 # narrow, medium and 4-line rows
+
+    # ---- configs[3]: 100 k queries against the resident shard
+    nq = 100_000
+    fasta, seqs = W.make_queries(nq, 150, seed=31)
+    q = pm.Queries(fasta)
+    hashes = q.hash_terms(1, 1)
+    plan, sure = W.plant_plan(hashes, nq, 120, sub, every=50)
+    ixs = []
+    for i, s in enumerate(sub):
+        ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, seed=SEED)
+        if i in plan:
+            ix.plant(*plan[i])
+        ixs.append(ix)
+    assert sum(i.info.device_bytes for i in ixs) > 130e9
+    res = pm.search(ixs, q, 0.7, nb_best_hits=100)
+    hits = res.hits()
+    st = res.stats
+    assert st.algorithmic_bytes == nq * 120 * sum(s.row_bytes for s in sub)
+    # one scan launch per row-width class, not per batch: 4-line, 3-line (if any), 2-line, and the mixed narrow launch
+    assert st.n_scan_launches <= 4 < len(sub)
+    real = hits[hits["doc"] != pm.PM_DOC_COUNT]
+    assert len(real) >= sure
+    checked = 0
+    for i, s in enumerate(sub):
+        planted = [qq for n, qq in enumerate(range(0, nq, 50)) if n % len(sub) == i][:2]
+        sample = sorted(set(planted + [i * 1009 + 7, nq - 1 - i]))
+        ov = _overlay(*plan[i]) if i in plan else {}
+        exp = _expected_hits(oracle, s, seqs, sample, ov, 0.7)
+        sel = real[(real["slot"] == i) & np.isin(real["query"], sample)]
+        assert [(int(x["query"]), int(x["doc"]), int(x["score"])) for x in sel] == exp, s.batch
+        checked += len(exp)
+    assert checked >= len(sub) * 2 * 4
+    a = pm.search(ixs[:17], q, 0.7, nb_best_hits=100, slot_base=0).hits()
+    b = pm.search(ixs[17:], q, 0.7, nb_best_hits=100, slot_base=17).hits()
+    assert np.array_equal(np.concatenate([a, b]), hits)
+    res.free()
+    q.free()
+
+    # ---- configs[4]: 1 M queries through the stage (03_match files + 04_filter FASTA)
+    nq = 1_000_000
+    fasta, seqs = W.make_queries(nq, 150, seed=5)
+    q = pm.Queries(fasta)
+    hashes = q.hash_terms(1, 1)
+    plan2, sure2 = W.plant_plan(hashes, nq, 120, sub, every=2500, docs_per_query=12)
+    del hashes
+    for i, ix in enumerate(ixs):
+        if i in plan2:
+            ix.plant(*plan2[i])
+    names = sorted(s.batch for s in sub)
+    by_name = {s.batch: (i, s) for i, s in enumerate(sub)}
+    src = MS.ResidentSource({s.batch: ixs[i] for i, s in enumerate(sub)})
+    report, merge = MS.run_stage(pm, names, list(range(len(names))), src, q, "Q", str(tmp_path / "03_match"), 0.7, 100,
+                                 want_merge=True)
+    assert report["groups"] == 1 and report["scan_launches"] <= 4 and report["queries"] == nq
+    out_fa = merge.emit().decode()
+    # sampled queries: planted ones (hits in one batch) and unplanted ones
+    planted_q = list(range(0, nq, 2500))[:6]
+    sample = planted_q + [1, 499_999, nq - 1]
+    expect = {}                                   # query -> {batch: [(doc, score)...]} after threshold, in cobs order
+    for b in names:
+        i, s = by_name[b]
+        ov = {}
+        for pl in (plan, plan2):
+            if i in pl:
+                for r, d in zip(pl[i][0].tolist(), pl[i][1].tolist()):
+                    ov.setdefault(r, []).append(d)
+        for (qq, d, v) in _expected_hits(oracle, s, seqs, sample, ov, 0.7):
+            expect.setdefault(qq, {}).setdefault(b, []).append((d, v))
+    assert sum(len(v) for v in expect.values()) >= 6            # the planted queries do hit
+    name_of = {b: [ixs[by_name[b][0]].doc_name(d) for d in range(by_name[b][1].n_docs)] for b in names}
+    for b in names[:3] + names[-2:] + sorted({bb for v in expect.values() for bb in v})[:4]:
+        text = gzip.open(tmp_path / "03_match" / f"{b}____Q.gz", "rt").read()
+        assert text.count("*q") == nq                           # every query has its header line in every file
+        blocks = _query_blocks(text)
+        for qq in sample:
+            mine_ = expect.get(qq, {}).get(b, [])
+            cobs = f"*q{qq:07d}\t{len(mine_)}\n" + "".join(f"{name_of[b][d]}\t{v}\n" for d, v in mine_)
+            assert "\n".join(blocks[f"q{qq:07d}"]) + "\n" == P.filter_text(cobs, 100), (b, qq)
+    # 04_filter: the 100 best (+ ties) over the shard's batches, ordered (-kmers, batch, ref)
+    fa_lines = out_fa.split("\n")
+    assert len(fa_lines) == 2 * nq + 1
+    for qq in sample:
+        items = []
+        for b, lst in expect.get(qq, {}).items():
+            kept = P.filter_text(f"*x\t{len(lst)}\n" + "".join(f"{name_of[b][d]}\t{v}\n" for d, v in lst), 100).split("\n")[1:-1]
+            items += [(-int(l.split("\t")[1]), b, l.split("\t")[0][1:]) for l in kept]
+        items.sort()
+        if len(items) > 100:
+            cut = 100
+            while cut < len(items) and items[cut][0] == items[99][0]:
+                cut += 1
+            items = items[:cut]
+        assert fa_lines[2 * qq] == f">q{qq:07d} " + ",".join(r for _, _, r in items)
+        assert fa_lines[2 * qq + 1] == seqs[qq].tobytes().decode()
+    for ix in ixs:
+        ix.free()

@@ -65,21 +65,52 @@ def effective_cpus():
     return max(1, n)
 
 
+def host_memory_gb():
+    """GB of host RAM this process may still take: MemAvailable, capped by what the cgroup leaves"""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, int(lim) - cur) if avail is not None else int(lim) - cur
+    except Exception:
+        pass
+    return (avail or 8 << 30) / 1e9
+
+
+def kernel_blob_hash():
+    """git blob id of the kernel source: PMC traffic figures are only valid for the code they were measured on"""
+    import hashlib
+    data = open(os.path.join(ROOT, "phylign_amd", "csrc", "pm_kernels.hip"), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
-    """Times oracle/cobs_oracle.c (kind "port": a restatement of the cobs classic
-    search, NOT bioconda cobs 0.2.1) on the host cores: same document counts per
-    batch (same algorithmic bytes per k-mer), rows scaled down to fit host RAM."""
+    """Times oracle/cobs_oracle.c (kind "port": a restatement of the cobs classic search, NOT bioconda
+    cobs 0.2.1) on the host cores, as SURVEY.md 8d / BASELINE.md section 2 specify it: index fully in
+    RAM (`--load-complete`), the largest row-scaled copy of the SAME batch shapes (same document counts =
+    same algorithmic bytes per k-mer) that fits the host-memory budget -- tens of GB, DRAM-resident, not
+    cache-resident --, -T = the cores the job may use, median of 3 runs, in both work partitions:
+    `queries` (threads split the queries) and `column_slabs` (cobs -T: hashes once per query, threads take
+    64-byte column slabs of the rows).  `value` is the faster of the two."""
     from oracle import oracle as O
     from phylign_amd import workload as W
     cores = effective_cpus()
     total = sum(s.index_bytes for s in shapes)
-    div = max(1, int(np.ceil(total / (sample_gb * 1e9))))
+    mem = host_memory_gb()
+    budget = sample_gb if sample_gb > 0 else min(48.0, 0.35 * mem)
+    div = max(1, int(np.ceil(total / (budget * 1e9))))
     small = W.scale_shapes(shapes, div)
     t0 = time.time()
-    mats = []
-    for s in small:
-        mats.append((s, O.synth_fill(661, s.batch_id, s.signature_size, s.n_docs, cores)))
+    mats = [(s, O.synth_fill(661, s.batch_id, s.signature_size, s.n_docs, cores)) for s in small]
     t_gen = time.time() - t0
+    sample_bytes = sum(m.nbytes for _, m in mats)
     hdrs = []
     for s, _ in mats:
         h = O.Header()
@@ -87,30 +118,50 @@ def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
         h.n_docs, h.signature_size, h.row_bytes = s.n_docs, s.signature_size, s.row_bytes
         hdrs.append(h)
 
-    def run(nq):
+    def run(nq, slabs):
         seqs = fasta_seqs[:nq].tobytes()
         t = time.time()
         hits = 0
         for (s, m), h in zip(mats, hdrs):
-            hits += O.baseline_run(m, s.row_bytes, h, seqs, qlen, nq, threshold, cores)
+            if slabs:
+                hits += O.baseline_run_slabs(m, s.row_bytes, h, seqs, qlen, nq, threshold, cores, 64)
+            else:
+                hits += O.baseline_run(m, s.row_bytes, h, seqs, qlen, nq, threshold, cores)
         return time.time() - t, hits
-    nq = min(256, len(fasta_seqs))
-    tt, _ = run(nq)
-    for _ in range(4):                  # grow the sample until it costs about target_s of CPU time
-        if tt >= 0.5 * target_s or nq >= len(fasta_seqs):
+    per_run = target_s / 6.0            # 2 partitions x 3 runs
+    nq = min(64 * cores, len(fasta_seqs))
+    tt, _ = run(nq, False)
+    for _ in range(4):                  # grow the query sample until one run costs about per_run seconds
+        if tt >= 0.6 * per_run or nq >= len(fasta_seqs):
             break
-        nq = int(min(len(fasta_seqs), max(nq * 2, nq * target_s / max(tt, 1e-6))))
-        tt, _ = run(nq)
+        nq = int(min(len(fasta_seqs), max(nq * 2, nq * per_run / max(tt, 1e-6))))
+        tt, _ = run(nq, False)
+    runs = {"queries": [], "column_slabs": []}
+    hits = {}
+    for _ in range(3):
+        for name, slabs in (("queries", False), ("column_slabs", True)):
+            t, hcount = run(nq, slabs)
+            runs[name].append(t)
+            hits[name] = hcount
+    assert hits["queries"] == hits["column_slabs"], "the two CPU partitions disagree"
     terms = nq * (qlen - 30)
     alg = terms * sum(s.row_bytes for s in shapes)
-    log(f"[cpu_baseline] gen {t_gen:.1f}s, {nq} queries in {tt:.2f}s on {cores} threads")
+    med = {k: float(np.median(v)) for k, v in runs.items()}
+    best = min(med, key=med.get)
+    log(f"[cpu_baseline] {sample_bytes / 1e9:.1f} GB sample generated in {t_gen:.1f}s, {nq} queries, medians "
+        + ", ".join(f"{k} {v:.2f}s" for k, v in med.items()) + f" on {cores} threads")
     return {
-        "value": terms / tt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-        "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity / cgroup quota): {cores} threads",
-        "sample": (f"{nq} of the same queries x all {len(shapes)} batch shapes with rows/{div} "
-                   f"({sum(s.index_bytes for s in small) / 1e9:.2f} GB resident in host RAM), "
-                   f"{tt:.1f}s wall, oracle/cobs_oracle.c COBS-restatement (not bioconda cobs 0.2.1)"),
-        "algorithmic_GBps": alg / tt / 1e9,
+        "value": terms / med[best], "unit": "k-mers/s", "cores": cores, "kind": "port", "runs": 3, "partition": best,
+        "partitions": {k: {"k-mers/s": terms / v, "algorithmic_GBps": alg / v / 1e9, "run_s": [round(x, 3) for x in runs[k]]}
+                       for k, v in med.items()},
+        "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity / cgroup quota): {cores} threads; "
+                f"{mem:.0f} GB of host RAM available to the job",
+        "sample_GB": sample_bytes / 1e9,
+        "sample": (f"{nq} of the same queries x all {len(shapes)} batch shapes with rows/{div}: {sample_bytes / 1e9:.1f} GB of "
+                   f"signatures resident in host RAM (DRAM-resident: the matrices are {sample_bytes / 2.56e8 / 2:.0f} x the host's "
+                   f"2 x 256 MB of L3), median of 3 runs per partition, {sum(sum(v) for v in runs.values()):.0f} s of timed CPU work; "
+                   f"oracle/cobs_oracle.c COBS-restatement (not bioconda cobs 0.2.1), index in RAM like --load-complete"),
+        "algorithmic_GBps": alg / med[best] / 1e9,
     }
 
 
@@ -132,13 +183,19 @@ def main():
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the other scan mode, the clustered variant and the fetched-bytes pass (profiling runs)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered (home batch) variant")
+    ap.add_argument("--no-l31", action="store_true", help="skip the 31-bp (one k-mer per query) legs")
+    ap.add_argument("--no-full-shard", action="store_true",
+                    help="skip the configs[3]/[4] leg (one rank's shard of the full 305-batch collection, generated after the headline set is freed)")
+    ap.add_argument("--full-shard-world", type=int, default=8)
+    ap.add_argument("--full-shard-rank", type=int, default=0)
     ap.add_argument("--clustered-multi", action="store_true",
                     help="run the clustered variant with N > 1 too (it ships ~0.5 GB of records per step to rank 0; "
                          "by default it is a single-GPU figure)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queueing the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-target-s", type=float, default=12.0)
-    ap.add_argument("--cpu-sample-gb", type=float, default=0.85)
+    ap.add_argument("--cpu-target-s", type=float, default=24.0, help="timed CPU work of the baseline (2 partitions x 3 runs)")
+    ap.add_argument("--cpu-sample-gb", type=float, default=0.0,
+                    help="host-RAM size of the CPU baseline's index sample (0 = min(48 GB, 35 %% of the RAM available to the job))")
     ap.add_argument("--dump-hits", default=None, help="rank 0 saves the ordered hit records of the headline mode (.npy)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: hold only the shard rank --emulate-rank would get in an N-way split "
@@ -239,9 +296,18 @@ def main():
     kept = []        # results whose pinned records are still referenced (freed at the end)
     phase = {"queue": 0.0, "wait": 0.0, "host": 0.0, "gather": 0.0}
 
+    def narrow_lines(infs):
+        """128-byte lines one k-mer touches in the batches of the mixed-width launch (rows of at most 256 bytes)"""
+        return sum(max(1, int(i.stride) // 128) for i in infs if i.stride <= 256)
+
+    # what the step functions below run on; swapped for the l31 and full_shard legs
+    cur = {"indexes": indexes, "q": q, "n_terms": n_terms, "rowsum": sum(s.row_bytes for s in shapes),
+           "slot_base": bases[part_id], "terms_per_q": terms_per_q, "tag": args.workload,
+           "narrow_lines_per_kmer": narrow_lines(infos)}
+
     def queue_step():
         t_a = time.perf_counter()
-        res = pm.search_async(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
+        res = pm.search_async(cur["indexes"], cur["q"], args.threshold, slot_base=cur["slot_base"], nb_best_hits=args.nb_best_hits)
         phase["queue"] += time.perf_counter() - t_a
         return res
 
@@ -287,8 +353,8 @@ def main():
         last["n_hits"] = len(host) if host is not None else None
         if groups is not None:
             for L in res.launches():
-                g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0])   # [algorithmic bytes, ms, launches, batches]
-                g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]
+                g = groups.setdefault(L["kernel"], [0.0, 0.0, 0, 0, 0])   # [algorithmic bytes, ms, launches, batches, queries]
+                g[0] += L["algorithmic_bytes"]; g[1] += L["ms"]; g[2] += 1; g[3] = L["n_batches"]; g[4] = L["n_queries"]
         if keep:
             # the records of the last step stay for the cross-mode comparison: keep the result alive
             # instead of copying hundreds of MB inside the timed region
@@ -323,54 +389,60 @@ def main():
         run_steps(steps, groups, keep_last=True)
         sync()
         elapsed = time.perf_counter() - t_start
+        rank_elapsed = [elapsed]
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return {"elapsed": elapsed, "groups": groups, "phase": dict(phase), "hits": last.get("hits"),
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_elapsed = [float(x.item()) for x in every]
+            elapsed = max(rank_elapsed)                       # the step of the job is the slowest rank's
+        return {"elapsed": elapsed, "rank_elapsed": rank_elapsed, "groups": groups, "phase": dict(phase), "hits": last.get("hits"),
                 "n_hits": last.get("n_hits"), "stats": last["stats"]}
 
     def fetched_pass(bound):
         """one untimed search with the in-kernel counter on: algorithmic bytes really gathered, per kernel"""
         pm.set_option("threshold_bound", 1 if bound else 0)
         pm.set_option("count_fetched", 1)
-        res = pm.search(indexes, q, args.threshold, slot_base=bases[part_id], nb_best_hits=args.nb_best_hits)
+        res = pm.search(cur["indexes"], cur["q"], args.threshold, slot_base=cur["slot_base"], nb_best_hits=args.nb_best_hits)
         out = {L["kernel"]: (L["fetched_bytes"], L["algorithmic_bytes"]) for L in res.launches()}
         res.free()
         pm.set_option("count_fetched", 0)
         return out
 
+    blob = kernel_blob_hash()
+
     def pmc_traffic(name, mode):
+        """HBM bytes per launch from the PMC passes committed under profiles/ (tools/run_pmc.sh): valid only for the
+        kernel source they were measured on (git blob of pm_kernels.hip), this workload and this query count"""
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("queries") == args.queries and tj.get("kernel") == name \
-                    and world == 1 and args.rows_divisor == 1:
-                return tj.get(mode, {}).get("hbm_bytes_per_launch")
+            if tj.get("pm_kernels_blob") != blob:
+                return None, f"profiles/pmc_traffic.json was measured on pm_kernels.hip blob {str(tj.get('pm_kernels_blob'))[:12]}, this is {blob[:12]}: re-run tools/run_pmc.sh"
+            if tj.get("workload") == cur["tag"] and tj.get("queries") == args.queries and world == 1 and args.rows_divisor == 1 \
+                    and args.qlen == tj.get("query_len", 150):
+                ent = tj.get("kernels", {}).get(name, {}).get(mode)
+                if ent:
+                    return ent.get("hbm_bytes_per_launch"), None
         except Exception:
             pass
-        return None
+        return None, None
 
-    def roofline_of(run, steps, mode, fetched):
-        """dominant scan kernel.  fetch_all_rows: algorithmic bytes per launch / hipEvent launch duration.
-        threshold_bound: the algorithmic bytes of the row chunks really gathered (in-kernel count) instead,
-        with the data-independent figure kept as `algorithmic_equivalent_GBps`."""
-        groups = run["groups"]
-        if not groups:
-            return None
-        name, (abytes, ms, launches, nb) = max(groups.items(), key=lambda kv: kv[1][1])
+    def roofline_entry(groups, name, steps, mode, fetched):
+        abytes, ms, launches, nb, nqk = groups[name]
         alg_per_launch = abytes / launches
         moved = alg_per_launch
         if mode == "threshold_bound":
             moved = fetched[name][0] if fetched and name in fetched else None
         achieved = moved / (ms / launches * 1e-3) / 1e9 if moved is not None else None
-        traffic = pmc_traffic(name, mode)
+        traffic, why = pmc_traffic(name, mode)
         r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": achieved / HBM_PEAK_GBPS if achieved is not None else None, "traffic": traffic, "kernel": name,
              "launches_per_step": launches / steps, "batches_per_launch": nb, "avg_launch_ms": ms / launches,
              "algorithmic_bytes_per_launch": alg_per_launch,
-             "bytes_gathered_per_launch": moved,
-             "all_scan_kernels_GBps": sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9}
+             "bytes_gathered_per_launch": moved}
+        if why:
+            r["traffic_note"] = why
         if mode == "threshold_bound":
             r["algorithmic_equivalent_GBps"] = alg_per_launch / (ms / launches * 1e-3) / 1e9
             r["note"] = ("achieved = algorithmic bytes of the row chunks this kernel really gathered (pm_set_option "
@@ -380,12 +452,45 @@ def main():
             r["hbm_GBps_from_traffic"] = traffic / (ms / launches * 1e-3) / 1e9
         return r
 
+    def roofline_of(run, steps, mode, fetched):
+        """dominant scan kernel.  fetch_all_rows: algorithmic bytes per launch / hipEvent launch duration.
+        threshold_bound: the algorithmic bytes of the row chunks really gathered (in-kernel count) instead,
+        with the data-independent figure kept as `algorithmic_equivalent_GBps`."""
+        groups = run["groups"]
+        if not groups:
+            return None
+        name = max(groups.items(), key=lambda kv: kv[1][1])[0]
+        r = roofline_entry(groups, name, steps, mode, fetched)
+        r["all_scan_kernels_GBps"] = sum(g[0] for g in groups.values()) / (sum(g[1] for g in groups.values()) * 1e-3) / 1e9
+        return r
+
+    def roofline_narrow_of(run, steps, mode, fetched):
+        """the kernel FURTHEST below the roofline: the mixed-width launch of the narrow batches (rows of at most 256
+        bytes).  Every lookup of a 13 ... 125-byte row moves one whole 128-byte line from HBM (measured: one
+        TCC_EA0_RDREQ_128B per lookup, profiles/r03/pmc_calibration_narrow.txt), so the wire carries
+        `wire_GBps_at_128B_per_line` while the algorithmic rate is what `achieved` says."""
+        groups = run["groups"]
+        names = [k for k in groups if "G=mixed" in k or any(f"G={g}," in k for g in (1, 2, 4, 8, 16))]
+        if not names:
+            return None
+        name = max(names, key=lambda k: groups[k][1])
+        r = roofline_entry(groups, name, steps, mode, fetched)
+        abytes, ms, launches, nb, nqk = groups[name]
+        if mode == "fetch_all_rows":
+            lines = cur["narrow_lines_per_kmer"] * nqk * cur["terms_per_q"]       # 128-byte lines touched per launch
+            r["lines_per_s"] = lines / (ms / launches * 1e-3)
+            r["wire_GBps_at_128B_per_line"] = lines * 128 / (ms / launches * 1e-3) / 1e9
+            r["wire_frac_of_peak"] = r["wire_GBps_at_128B_per_line"] / HBM_PEAK_GBPS
+        return r
+
     def summary(run, steps, mode, fetched):
         el = run["elapsed"] / steps
-        alg_total = sum(s.row_bytes for s in shapes) * n_terms
-        out = {"value": n_terms / el, "unit": "k-mers/s", "ms_per_step": el * 1e3,
-               "hbm_fraction_whole_step_algorithmic": alg_total / el / (HBM_PEAK_GBPS * 1e9 * world),
+        alg_total = cur["rowsum"] * cur["n_terms"]
+        frac_key = "hbm_fraction_whole_step_algorithmic" if mode == "fetch_all_rows" else "whole_step_algorithmic_equivalent_over_peak"
+        out = {"value": cur["n_terms"] / el, "unit": "k-mers/s", "ms_per_step": el * 1e3,
+               frac_key: alg_total / el / (HBM_PEAK_GBPS * 1e9 * world),
                "roofline": roofline_of(run, steps, mode, fetched),
+               "roofline_narrow": roofline_narrow_of(run, steps, mode, fetched),
                "hits": run["n_hits"],
                "rank0_ms": {"kernels_total": run["stats"].ms_total,
                             "host_wait_for_gpu": run["phase"]["wait"] / steps * 1e3,
@@ -408,6 +513,20 @@ def main():
             assert f == a, f"{k}: fetch-all scan gathered {f} bytes, algorithmic bytes are {a}"
     sum_head = summary(run_head, args.steps, head, fetched_head)
     st_head = run_head["stats"]
+
+    # ---- who took part (N > 1): a real all_reduce on device tensors counts the RCCL ranks, every rank reports the
+    # GPU that holds its matrices and its own time for the K steps
+    participants = {"backend": backend if world > 1 else None, "rccl_ranks": None,
+                    "rank_ms_per_step": [e / args.steps * 1e3 for e in run_head["rank_elapsed"]],
+                    "rank_devices": [indexes[0].device if indexes else local_rank]}
+    if world > 1:
+        ddev = "cuda" if backend == "nccl" else "cpu"
+        one = torch.ones(1, dtype=torch.int32, device=ddev)
+        dist.all_reduce(one)
+        devs = [torch.zeros(2, dtype=torch.int32, device=ddev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([indexes[0].device if indexes else -1, len(indexes)], dtype=torch.int32, device=ddev))
+        participants.update({"rccl_ranks": int(one.item()) if backend == "nccl" else None, "ranks": int(one.item()),
+                             "rank_devices": [int(d[0].item()) for d in devs], "rank_batches": [int(d[1].item()) for d in devs]})
 
     sum_other = None
     ok = True
@@ -447,6 +566,105 @@ def main():
                                                                    clustered["fetch_all_rows"]["value"])
     pm.set_option("threshold_bound", 1)
 
+    # ---- BASELINE configs[1] read literally: "10k synthetic 31-mer queries" = ONE k-mer per query (hit <=> bit
+    # set: with Bernoulli(1/4) signatures a quarter of all documents match every query, so this leg is bound by
+    # writing hit records, not by the scan).  (a) config 2: one batch, latency of one query set; (b) the resident
+    # index set of this run, k-mers/s.
+    l31 = None
+    if full and not args.no_l31 and world == 1 and args.qlen != 31:
+        l31 = {}
+        fasta31, _ = W.make_queries(10000, 31, seed=32)
+        q31 = pm.Queries(fasta31, term_size=31)
+        ba = [ix for pos, ix in zip(mine, indexes) if shapes[pos].batch == "bacillus_anthracis__01"]
+        if ba:
+            lat, st31, nrec = [], None, 0
+            for i in range(8):
+                t_a = time.perf_counter()
+                r = pm.search(ba, q31, args.threshold, nb_best_hits=args.nb_best_hits)
+                h = r.hits(copy=False)
+                lat.append(time.perf_counter() - t_a)
+                st31, nrec = r.stats, len(h)
+                r.free()
+            l31["config2"] = {"workload": "bacillus_anthracis__01 shape (664 documents, 83-byte rows), 10 000 x 31-bp queries, threshold 0.7",
+                              "latency_ms_per_query_set_median": float(np.median(lat[2:]) * 1e3),
+                              "kernels_ms": st31.ms_total, "hash_ms": st31.ms_hash, "scan_ms": st31.ms_scan,
+                              "kmers_per_s": 10000 / float(np.median(lat[2:])), "hit_records": nrec,
+                              "note": "wall time of pm_search + records on the host (pinned); one k-mer per query"}
+        # the resident set: as many 31-mer queries as keep one search near 2^26 hit records (1 GB of them)
+        docs = sum(i.n_docs for i in infos)
+        nq31 = int(max(256, min(10000, (1 << 26) // max(1, docs // 4))))
+        fasta31b, _ = W.make_queries(nq31, 31, seed=33)
+        q31b = pm.Queries(fasta31b, term_size=31)
+        saved = dict(cur)
+        cur.update({"q": q31b, "n_terms": nq31, "terms_per_q": 1, "tag": args.workload + "/l31"})
+        try:
+            r31 = timed_run(False, 2, max(3, min(args.steps, 5)))
+            s31 = summary(r31, max(3, min(args.steps, 5)), "fetch_all_rows", None)
+            l31["resident_set"] = {"workload": f"{len(indexes)} resident batches ({docs} documents), {nq31} x 31-bp queries (query count capped "
+                                               "so that one search stays near 2^26 hit records)",
+                                   "value": s31["value"], "unit": "k-mers/s", "ms_per_step": s31["ms_per_step"],
+                                   "hit_records_per_step": s31["hits"], "roofline": s31["roofline"],
+                                   "note": "output-bound: every query matches ~1/4 of all documents (Bernoulli(1/4) signatures, "
+                                           "threshold 0.7 of 1 k-mer = 1); records are 16 bytes each"}
+        finally:
+            cur.clear(); cur.update(saved)
+        q31.free(); q31b.free()
+
+    # ---- BASELINE configs[3] / configs[4] on their own workload: the shard ONE rank holds when all 305 batches of
+    # batches_full.txt are split over 8 GPUs (38 batches, ~135 GB), 100 k queries (config 4's per-rank step) and
+    # 1 M queries (config 5's match-only time; the end-to-end figure is tools/e2e_config5.py).  The headline set is
+    # freed first: both do not fit one GPU together.
+    full_shard = None
+    if full and not args.no_full_shard and world == 1 and args.workload == "config3" and args.rows_divisor == 1:
+        for ix in indexes:
+            ix.free()
+        indexes = []
+        t0 = time.time()
+        fshapes = W.select("full")
+        fmine = W.assign_batches(fshapes, args.full_shard_world)[args.full_shard_rank]
+        fsub = [fshapes[p] for p in fmine]
+        fplan, fsure = W.plant_plan(q.hash_terms(1, 1), nq, terms_per_q, fsub)
+        for i, sshape in enumerate(fsub):
+            ix = pm.Index.synth(sshape.batch_id, sshape.n_docs, sshape.signature_size, 1, 31, 661, layout=args.layout)
+            if i in fplan:
+                ix.plant(*fplan[i])
+            indexes.append(ix)
+        finfos = [ix.info for ix in indexes]
+        log(f"[bench] full_shard: {len(indexes)} batches, {sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
+        saved = dict(cur)
+        cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fsub), "slot_base": 0,
+                    "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_kmer": narrow_lines(finfos)})
+        fs_steps = max(3, min(args.steps, 10))
+        full_shard = {"workload": f"rank {args.full_shard_rank} of {args.full_shard_world} of batches_full.txt (305 batches, 1.06 TB, 82 741 row "
+                                  f"bytes per k-mer): {len(fsub)} batches, {sum(sh.index_bytes for sh in fsub) / 1e9:.1f} GB on disk, "
+                                  f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, {cur['rowsum']} row bytes per k-mer; "
+                                  f"{nq} x {args.qlen} bp queries",
+                      "planted_pairs_at_or_above_threshold": fsure}
+        f_runs = {}
+        for m in modes:
+            r = timed_run(m == "threshold_bound", 2, fs_steps)
+            f_runs[m] = r
+            full_shard[m] = summary(r, fs_steps, m, fetched_pass(m == "threshold_bound"))
+        same = bool(np.array_equal(f_runs[modes[0]]["hits"], f_runs[modes[1]]["hits"]))
+        n_real = int(np.count_nonzero(f_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
+        full_shard["hits_identical"] = same
+        ok = ok and same and n_real >= fsure
+        # config 5's query count: match-only rate at 1 M queries
+        t0 = time.time()
+        fasta1m, _ = W.make_queries(1_000_000, args.qlen, seed=5)
+        q1m = pm.Queries(fasta1m, term_size=31)
+        del fasta1m
+        cur.update({"q": q1m, "n_terms": 1_000_000 * terms_per_q, "tag": cur["tag"] + "/1M"})
+        full_shard["queries_1M"] = {"setup_s": round(time.time() - t0, 2)}
+        for m in modes:
+            r = timed_run(m == "threshold_bound", 1, 2)
+            sm = summary(r, 2, m, None)
+            full_shard["queries_1M"][m] = {"value": sm["value"], "unit": "k-mers/s", "ms_per_step": sm["ms_per_step"],
+                                           "hits": sm["hits"], "roofline": sm["roofline"], "roofline_narrow": sm["roofline_narrow"]}
+        cur.clear(); cur.update(saved)
+        q1m.free()
+        pm.set_option("threshold_bound", 1)
+
     ph = run_head["phase"]
     out = {
         "metric": "query k-mers matched/sec vs 661k-shaped COBS index",
@@ -471,7 +689,7 @@ def main():
                        "did not move); since round 2 `value`/`roofline` are the fetch-every-row scan and the product "
                        "default is the `threshold_bound` object -- compare that one with round 1"
                        if head == "fetch_all_rows" else "headline switched to the data-dependent threshold_bound mode by --headline"),
-        "hbm_fraction_whole_step": sum_head["hbm_fraction_whole_step_algorithmic"],
+        "hbm_fraction_whole_step": sum_head.get("hbm_fraction_whole_step_algorithmic", sum_head.get("whole_step_algorithmic_equivalent_over_peak")),
         "hits": sum_head["hits"],
         "planted_pairs_at_or_above_threshold": sure_hits,
         "rank0_ms": {"kernels_total": st_head.ms_total, "hash": st_head.ms_hash, "scan": st_head.ms_scan,
@@ -481,10 +699,15 @@ def main():
                      "hit_gather": ph["gather"] / args.steps * 1e3},
         "scan_launches": {k: {"launches_per_step": v[2] / args.steps, "batches": v[3], "avg_ms": v[1] / v[2],
                               "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in run_head["groups"].items()},
+        "pm_kernels_blob": blob,
+        "participants": participants,
         "roofline": sum_head["roofline"],
+        "roofline_narrow": sum_head["roofline_narrow"],
         "arithmetic": "bitwise AND / carry-save adders on u32 words (bit-sliced per-document counters), u64 integer hashing",
         other: sum_other,
         "clustered": clustered,
+        "l31": l31,
+        "full_shard": full_shard,
     }
     if args.emulate_world:
         out["emulated_shard"] = f"rank {part_id} of {nparts}"

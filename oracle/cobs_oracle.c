@@ -508,3 +508,90 @@ uint64_t orc_baseline_run(const uint8_t* matrix, uint64_t stride, const orc_head
     free(args); free(th);
     return hits;
 }
+
+/* The same work partitioned the way `cobs query -T` partitions it (upstream classic_search.cpp: the
+ * term hashes of a query are computed once, then threads take COLUMN SLABS of the rows and count
+ * every term's slab into the slab's scores): phase 1 maps every k-mer of the sample to its row
+ * (threads split the queries), phase 2 hands out (column slab of `slab_bytes` row bytes, chunk of
+ * queries) units -- a narrow row is a single slab, so the query chunks keep all threads busy where
+ * cobs would leave T - 1 of them idle.  Results equal orc_baseline_run's. */
+typedef struct {
+    const uint8_t* matrix; uint64_t stride; const orc_header_t* h; const char* seqs;
+    size_t qlen, nq, nt, slab_bytes, n_slabs, q_chunk, n_units; double threshold;
+    uint64_t* rows; volatile long* next; uint64_t hits; int phase; size_t q0, q1;
+} sl_arg;
+static void* sl_worker(void* vp) {
+    sl_arg* a = (sl_arg*)vp; const orc_header_t* h = a->h;
+    if (a->phase == 1) {
+        uint64_t* hs = (uint64_t*)malloc(a->nt * h->num_hashes * 8);
+        for (size_t q = a->q0; q < a->q1; q++) {
+            if (orc_create_hashes(a->seqs + q * a->qlen, a->qlen, h->term_size, h->canonicalize, h->num_hashes, hs)) continue;
+            for (size_t i = 0; i < a->nt * h->num_hashes; i++) a->rows[q * a->nt * h->num_hashes + i] = hs[i] % h->signature_size;
+        }
+        free(hs);
+        return NULL;
+    }
+    const size_t rb = (size_t)h->row_bytes, nh = (size_t)h->num_hashes;
+    __m128i* cnt = (__m128i*)aligned_alloc(16, a->slab_bytes * 16);
+    uint8_t* acc = (uint8_t*)malloc(a->slab_bytes);
+    const uint32_t T = orc_threshold(a->threshold, a->nt);
+    for (;;) {
+        const long u = __sync_fetch_and_add(a->next, 1);
+        if ((size_t)u >= a->n_units) break;
+        const size_t slab = (size_t)u % a->n_slabs, chunk = (size_t)u / a->n_slabs;
+        const size_t b0 = slab * a->slab_bytes, b1 = b0 + a->slab_bytes < rb ? b0 + a->slab_bytes : rb, w = b1 - b0;
+        const size_t qa = chunk * a->q_chunk, qb = qa + a->q_chunk < a->nq ? qa + a->q_chunk : a->nq;
+        for (size_t q = qa; q < qb; q++) {
+            memset(cnt, 0, w * 16);
+            const uint64_t* rq = a->rows + q * a->nt * nh;
+            for (size_t i = 0; i < a->nt; i++) {
+                const uint8_t* src = a->matrix + rq[i * nh] * a->stride + b0;
+                if (nh > 1) {
+                    memcpy(acc, src, w);
+                    for (size_t j = 1; j < nh; j++) {
+                        const uint8_t* rj = a->matrix + rq[i * nh + j] * a->stride + b0;
+                        for (size_t b = 0; b < w; b++) acc[b] &= rj[b];
+                    }
+                    src = acc;
+                }
+                for (size_t b = 0; b < w; b++) cnt[b] = _mm_add_epi16(cnt[b], g_expand[src[b]]);
+            }
+            const uint16_t* c16 = (const uint16_t*)cnt;
+            const size_t d1 = b1 * 8 < h->n_docs ? b1 * 8 : h->n_docs;
+            for (size_t d = b0 * 8; d < d1; d++) a->hits += (c16[d - b0 * 8] >= T);
+        }
+    }
+    free(acc); free(cnt);
+    return NULL;
+}
+uint64_t orc_baseline_run_slabs(const uint8_t* matrix, uint64_t stride, const orc_header_t* h,
+                                const char* seqs, size_t qlen, size_t n_queries, double threshold,
+                                int threads, size_t slab_bytes) {
+    pthread_once(&g_expand_once, init_expand);
+    if (threads < 1) threads = 1;
+    if (slab_bytes < 1) slab_bytes = 64;
+    if (qlen < h->term_size || qlen - h->term_size + 1 > 65535 || n_queries == 0) return 0;
+    const size_t nt = qlen - h->term_size + 1;
+    uint64_t* rows = (uint64_t*)malloc(n_queries * nt * h->num_hashes * 8);
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    sl_arg* args = (sl_arg*)calloc((size_t)threads, sizeof(sl_arg));
+    volatile long next = 0;
+    const size_t n_slabs = ((size_t)h->row_bytes + slab_bytes - 1) / slab_bytes;
+    size_t chunks = ((size_t)threads * 4 + n_slabs - 1) / n_slabs;          /* >= 4 units per thread */
+    if (chunks > n_queries) chunks = n_queries;
+    const size_t q_chunk = (n_queries + chunks - 1) / chunks;
+    chunks = (n_queries + q_chunk - 1) / q_chunk;
+    for (int phase = 1; phase <= 2; phase++) {
+        for (int t = 0; t < threads; t++) {
+            args[t] = (sl_arg){matrix, stride, h, seqs, qlen, n_queries, nt, slab_bytes, n_slabs, q_chunk, n_slabs * chunks,
+                               threshold, rows, &next, 0, phase,
+                               n_queries * (size_t)t / (size_t)threads, n_queries * (size_t)(t + 1) / (size_t)threads};
+            pthread_create(&th[t], NULL, sl_worker, &args[t]);
+        }
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    uint64_t hits = 0;
+    for (int t = 0; t < threads; t++) hits += args[t].hits;
+    free(args); free(th); free(rows);
+    return hits;
+}

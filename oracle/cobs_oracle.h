@@ -108,6 +108,11 @@ uint64_t orc_baseline_run(const uint8_t* matrix, uint64_t stride,
                           const orc_header_t* h, const char* seqs,
                           size_t qlen, size_t n_queries, double threshold,
                           int threads);
+/* the same search with the work split into column slabs like `cobs query -T` (hashes once per query,
+ * threads count (slab of slab_bytes row bytes, chunk of queries) units); returns the same count */
+uint64_t orc_baseline_run_slabs(const uint8_t* matrix, uint64_t stride, const orc_header_t* h,
+                                const char* seqs, size_t qlen, size_t n_queries, double threshold,
+                                int threads, size_t slab_bytes);
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,9 @@ def lib():
         L.orc_baseline_run.restype = C.c_uint64
         L.orc_baseline_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Header), C.c_char_p, C.c_size_t,
                                        C.c_size_t, C.c_double, C.c_int]
+        L.orc_baseline_run_slabs.restype = C.c_uint64
+        L.orc_baseline_run_slabs.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Header), C.c_char_p, C.c_size_t,
+                                             C.c_size_t, C.c_double, C.c_int, C.c_size_t]
         _lib = L
     return _lib
 
@@ -243,3 +246,9 @@ def synth_fill(seed: int, batch: int, n_rows: int, n_docs: int, threads: int = 1
 
 def baseline_run(matrix, stride, h: Header, seqs: bytes, qlen: int, n_queries: int, thr: float, threads: int) -> int:
     return lib().orc_baseline_run(matrix.ctypes.data, stride, C.byref(h), seqs, qlen, n_queries, thr, threads)
+
+
+def baseline_run_slabs(matrix, stride, h: Header, seqs: bytes, qlen: int, n_queries: int, thr: float, threads: int,
+                       slab_bytes: int = 64) -> int:
+    """baseline_run with the work split into column slabs the way `cobs query -T` splits it"""
+    return lib().orc_baseline_run_slabs(matrix.ctypes.data, stride, C.byref(h), seqs, qlen, n_queries, thr, threads, slab_bytes)

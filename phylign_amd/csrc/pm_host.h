@@ -28,11 +28,12 @@
 
 using namespace pm;
 
-// counter-width classes: queries of < 2^7, 2^10, 2^16, 2^20, 2^24 k-mers get bit-sliced per-document
+// counter-width classes: queries of < 2^3, 2^7, 2^10, 2^16, 2^20, 2^24 k-mers get bit-sliced per-document
 // counters of that many planes (one k_scan instantiation each), so short reads never pay for a
-// long gene or plasmid in the same FASTA
-constexpr int kNumClasses = 5;
-static const int kPlaneClass[kNumClasses] = {7, 10, 16, 20, 24};
+// long gene or plasmid in the same FASTA, and a query of 1 ... 7 k-mers (BASELINE configs[1]: "31-mer
+// queries" = one k-mer each, hit <=> bit set) carries three planes instead of seven
+constexpr int kNumClasses = 6;
+static const int kPlaneClass[kNumClasses] = {3, 7, 10, 16, 20, 24};
 
 // ------------------------------------------------------------------ errors
 // sets the calling thread's pm_last_error() text, returns `code`

@@ -655,6 +655,7 @@ static hipError_t scan_dispatch_nh(const ScanArgs& a, uint32_t slabs, hipStream_
 template <int G>
 static hipError_t scan_dispatch_p(const ScanArgs& a, int planes, uint32_t slabs, hipStream_t st) {
     switch (planes) {
+        case 3:  return scan_dispatch_nh<G, 3>(a, slabs, st);
         case 7:  return scan_dispatch_nh<G, 7>(a, slabs, st);
         case 10: return scan_dispatch_nh<G, 10>(a, slabs, st);
         case 16: return scan_dispatch_nh<G, 16>(a, slabs, st);

@@ -236,7 +236,8 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     // 0 = plain form, else the number of lane groups that may share a query (power of two, >= 8)
     std::vector<uint32_t> use_wq(groups.size() * kNumClasses, 0);
     for (size_t gi = 0; gi < groups.size(); ++gi)
-        for (int c = 1; c < kNumClasses; ++c) {            // classes of 128+ k-mers per query
+        for (int c = 0; c < kNumClasses; ++c) {
+            if (kPlaneClass[c] < 10) continue;              // the form exists for classes of 128+ k-mers per query
             const uint32_t nqc = q->class_begin[c + 1] - q->class_begin[c];
             if (nqc == 0 || g_wide_query == 2) continue;
             uint64_t waves = 0, lanes = 0;

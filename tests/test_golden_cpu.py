@@ -677,3 +677,25 @@ def test_unprepared_queries_are_rejected_without_normalise():
     with pytest.raises(pm.PMError) as e:
         pm.Queries(b">r\nacgtacgtacgtacgtacgtacgtacgtacgtacgt\n", term_size=31)
     assert e.value.code == -6
+
+
+def test_cpu_baseline_partitions_agree_with_the_oracle_scores(oracle):
+    """bench.py's cpu_baseline legs (query partition and cobs -T-like column slabs) count exactly the
+    documents the oracle's scoring + threshold rule selects"""
+    O = oracle
+    rng = np.random.default_rng(3)
+    for n_docs, S in ((1000, 3000), (22 * 8 - 3, 2500)):
+        m = O.synth_fill(661, 7, S, n_docs, 2)
+        h = O.Header()
+        h.term_size, h.canonicalize, h.num_hashes = 31, 1, 1
+        h.n_docs, h.signature_size, h.row_bytes = n_docs, S, (n_docs + 7) // 8
+        nq, qlen = 37, 150
+        seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(nq, qlen))]
+        want = 0
+        for i in range(nq):
+            sc = O.scores_rows(lambda r: m[r], h, seqs[i].tobytes())
+            want += len(O.select(sc, qlen - 30, 0.2))
+        assert want > 0
+        assert O.baseline_run(m, h.row_bytes, h, seqs.tobytes(), qlen, nq, 0.2, 3) == want
+        for slab in (16, 64, 1000):
+            assert O.baseline_run_slabs(m, h.row_bytes, h, seqs.tobytes(), qlen, nq, 0.2, 3, slab) == want

@@ -82,9 +82,9 @@ def test_query_text_bit_exact(pm, oracle, case, layout):
 
 
 def test_mixed_lengths_and_plane_classes(pm, oracle):
-    """queries of 1 k-mer ... 1.05 M k-mers in one FASTA: every counter-width class (7/10/16/20/24 planes)."""
+    """queries of 1 k-mer ... 1.05 M k-mers in one FASTA: every counter-width class (3/7/10/16/20/24 planes)."""
     rng = np.random.default_rng(5)
-    lens = [31, 32, 100, 157, 158, 160, 400, 1053, 1054, 3000, 65565, 65566, 70000, 150, 31, 1048605, 1048606]
+    lens = [31, 32, 37, 38, 100, 157, 158, 160, 400, 1053, 1054, 3000, 65565, 65566, 70000, 150, 31, 1048605, 1048606]
     queries = [(f"g{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
     plant = [(i, int(rng.integers(0, 200)), f) for i in range(len(lens)) for f in (1.0, 0.7, 0.5)]
     index, fasta, _ = build_case(oracle, rng, 200, 9000, queries, plant=plant, density=0.3)
@@ -92,7 +92,7 @@ def test_mixed_lengths_and_plane_classes(pm, oracle):
     for thr in (0.7, 0.28):
         assert pm.query_text(ix, fasta, thr) == oracle.query_file(index, fasta, thr)
     res = pm.search([ix], pm.Queries(fasta), 0.7)
-    assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"7", "10", "16", "20", "24"}
+    assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"3", "7", "10", "16", "20", "24"}
 
 
 def test_fasta_record_rules(pm, oracle):
@@ -329,7 +329,7 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
     """several narrow batches of different lane-group widths (one mixed-width launch) x queries of
     every counter-width class, plus a wide and a column-slab batch, in ONE search"""
     rng = np.random.default_rng(77)
-    lens = [31, 150, 150, 158, 159, 400, 1054, 1055, 3000, 65566, 150, 40]
+    lens = [31, 37, 38, 150, 150, 158, 159, 400, 1054, 1055, 3000, 65566, 150, 40]
     queries = [(f"w{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
     shapes = [(13, 900), (100, 700), (200, 800), (300, 600), (664, 900), (1500, 500), (4000, 400), (9001, 300), (50, 1000)]
     cases = []
@@ -344,7 +344,7 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
         res = pm.search(ixs, q, thr, slot_base=5)
         kernels = [L["kernel"] for L in res.launches()]
         assert any("G=mixed" in k for k in kernels) and any("G=32" in k for k in kernels)
-        assert {k.split("P=")[1].split(",")[0] for k in kernels} == {"7", "10", "16", "20"}
+        assert {k.split("P=")[1].split(",")[0] for k in kernels} == {"3", "7", "10", "16", "20"}
         hits = res.hits()
         for s, (index, _, _) in enumerate(cases):
             assert pm.format_hits(ixs[s], q, hits, slot=5 + s) == oracle.query_file(index, fasta, thr), shapes[s]

@@ -212,6 +212,8 @@ int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
  * previous search meanwhile.  Several searches may be in flight (they run in order);
  * the index array may be released after the call, the indexes and the query set must
  * stay alive until the result is waited for.  Every pm_result_* getter waits itself. */
+/* Threads: searches may be queued from several threads, but ONE pm_queries_t must not be searched (or hashed,
+ * or freed) from two threads at the same time -- the handle caches its hashes and per-query thresholds. */
 int  pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                      double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out);
 int  pm_result_wait(pm_result_t* r);

@@ -11,6 +11,7 @@
 #include "pm_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>

@@ -62,6 +62,16 @@ static uint64_t stride_aligned(uint64_t rb) {
     return (rb + 127) / 128 * 128;
 }
 
+// PM_EFORMAT unless `rows` rows of `stride` bytes are a size this GPU could ever hold
+static int check_matrix_size(uint64_t rows, uint64_t stride) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return fail(PM_EHIP, "hipMemGetInfo failed");
+    if (stride == 0 || rows > (uint64_t)tot / stride)
+        return fail(PM_EFORMAT, "index header asks for %llu rows of %llu bytes: more than this GPU's %llu bytes of HBM (corrupt header?)",
+                    (unsigned long long)rows, (unsigned long long)stride, (unsigned long long)tot);
+    return PM_OK;
+}
+
 static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, bool want_matrix) {
     pm_index_info_t& in = ix->info;
     in.term_size = h.term_size; in.canonicalize = h.canon; in.signature_size = h.sig;
@@ -73,6 +83,12 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     if (in.row_bytes == 0) return fail(PM_EFORMAT, "index holds no documents");
     uint64_t sc = stride_compact(in.row_bytes), sa = stride_aligned(in.row_bytes);
     uint64_t stride = sc;
+    // signature_size comes straight from the file: no row count may make `rows x stride` wrap (a crafted header with
+    // signature_size >= 2^60 would otherwise get a tiny allocation and the upload would write past it) or exceed HBM
+    {
+        int rc_sz = check_matrix_size(h.sig, sa);
+        if (rc_sz) return rc_sz;
+    }
     // loaders run concurrently (match_stage --loaders): the "does the aligned layout still fit"
     // question and the allocation that answers it are one critical section
     static std::mutex alloc_mu;
@@ -91,8 +107,11 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     ix->g = (int)pow2ceil(lanes);
     ix->slabs = (uint32_t)((stride + 1023) / 1024);
     hipError_t e = hipMalloc((void**)&ix->d_matrix, in.device_bytes);
-    if (e != hipSuccess) return fail(PM_ENOMEM, "hipMalloc(%llu bytes) for the signature matrix failed: %s",
-                                     (unsigned long long)in.device_bytes, hipGetErrorString(e));
+    if (e != hipSuccess || !ix->d_matrix) {
+        ix->d_matrix = nullptr;
+        return fail(PM_ENOMEM, "hipMalloc(%llu bytes) for the signature matrix failed: %s",
+                    (unsigned long long)in.device_bytes, e != hipSuccess ? hipGetErrorString(e) : "null pointer");
+    }
     in.has_matrix = 1;
     return PM_OK;
 }
@@ -316,10 +335,14 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
             in.stride = stride; in.device_bytes = pc.sig[p] * stride;
             part->g = (int)pow2ceil((std::min<uint64_t>(stride, 1024) + 15) / 16);
             part->slabs = (uint32_t)((stride + 1023) / 1024);
-            hipError_t e = hipMalloc((void**)&part->d_matrix, in.device_bytes);
-            if (e != hipSuccess) rc = fail(PM_ENOMEM, "hipMalloc(%llu bytes) for sub-index %u failed: %s",
-                                           (unsigned long long)in.device_bytes, p, hipGetErrorString(e));
-            else { in.has_matrix = 1; rc = stream_matrix(rd, part, pc.page, pc.sig[p]); }
+            rc = check_matrix_size(pc.sig[p], sa);
+            hipError_t e = rc ? hipSuccess : hipMalloc((void**)&part->d_matrix, in.device_bytes);
+            if (rc) {}
+            else if (e != hipSuccess || !part->d_matrix) {
+                part->d_matrix = nullptr;
+                rc = fail(PM_ENOMEM, "hipMalloc(%llu bytes) for sub-index %u failed: %s",
+                          (unsigned long long)in.device_bytes, p, e != hipSuccess ? hipGetErrorString(e) : "null pointer");
+            } else { in.has_matrix = 1; rc = stream_matrix(rd, part, pc.page, pc.sig[p]); }
         }
         if (rc) { pm_index_free(ix); return rc; }
         ix->info.device_bytes += part->info.device_bytes;

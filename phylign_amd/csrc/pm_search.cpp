@@ -32,9 +32,9 @@ static int take_hit_buffer(uint64_t cap, HitBuf* out) {
     if (cap >= 0xFFFFFFF0ull) return fail(PM_ERANGE, "more than 2^32 hit records in one search: split the query set");
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        size_t best = g_ctx.free_hits.size();          // the largest pooled buffer that is big enough
-        for (size_t i = 0; i < g_ctx.free_hits.size(); ++i)
-            if (g_ctx.free_hits[i].cap >= cap && (best == g_ctx.free_hits.size() || g_ctx.free_hits[i].cap > g_ctx.free_hits[best].cap))
+        size_t best = g_ctx.free_hits.size();          // the smallest pooled buffer that is big enough (a small request must
+        for (size_t i = 0; i < g_ctx.free_hits.size(); ++i)   // not take the buffer the next large search needs)
+            if (g_ctx.free_hits[i].cap >= cap && (best == g_ctx.free_hits.size() || g_ctx.free_hits[i].cap < g_ctx.free_hits[best].cap))
                 best = i;
         if (best != g_ctx.free_hits.size()) {
             *out = g_ctx.free_hits[best];
@@ -120,13 +120,14 @@ struct pm_result {
     // in-flight state
     Workspace* ws = nullptr;
     bool pending = false;
+    int failed = 0;                               // error code of a wait that failed: every later getter reports it
     int attempt = 0;
     size_t nev = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> lev;
     unsigned long long* h_fetch = nullptr;       // pinned [launch][kFetchShards] when "count_fetched" is on
     // ordered form (ensure_ordered): records permuted on the device into (slot, query) run order
-    bool ordered = false;
+    std::atomic<bool> ordered{false};              // double-checked under g_order_mu
     HitBuf d_ord{nullptr, 0};
     uint64_t n_out = 0;
     std::vector<std::pair<uint64_t, uint64_t>> fixups;   // [begin, end) of (slot, query) groups merged from several runs
@@ -384,24 +385,35 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     return PM_OK;
 }
 
+static int result_wait_impl(pm_result_t* r);
 extern "C" int pm_result_wait(pm_result_t* r) {
     if (!r) return fail(PM_EINVAL, "bad argument");
-    if (!r->pending) return PM_OK;
+    if (!r->pending) return r->failed ? fail(r->failed, "this search failed earlier") : PM_OK;
     NEED_DEV();
+    const int rc = result_wait_impl(r);
+    if (rc && r->pending) {                     // a HIP call failed half way: the result is dead, not "still pending"
+        (void)hipStreamSynchronize(g_ctx.stream);
+        r->pending = false;
+        r->failed = rc;
+        result_release(r);
+    }
+    return rc;
+}
+static int result_wait_impl(pm_result_t* r) {
     for (;;) {
         HIPCHK(hipEventSynchronize(r->ws->done));
         const unsigned long long cnt = r->ws->h_cnt[0], runs = r->ws->h_cnt[1];
         if (cnt <= r->cap) {
             r->n_records = cnt; r->n_runs = runs;
-            if (cnt > g_ctx.hit_hint) g_ctx.hit_hint = cnt;
+            { std::lock_guard<std::mutex> lk(g_pool_mu); if (cnt > g_ctx.hit_hint) g_ctx.hit_hint = cnt; }
             break;
         }
         // hit buffer too small: grow to the exact count and run the job again
-        if (r->attempt >= 1) { r->pending = false; result_release(r); return fail(PM_EHIP, "hit count changed between runs"); }
+        if (r->attempt >= 1) { r->pending = false; r->failed = PM_EHIP; result_release(r); return fail(PM_EHIP, "hit count changed between runs"); }
         r->attempt++;
         (void)hipFree(r->d_hits); r->d_hits = nullptr; r->cap = 0;
         int rc = enqueue_search(r, cnt);
-        if (rc) { r->pending = false; result_release(r); return rc; }
+        if (rc) { (void)hipStreamSynchronize(g_ctx.stream); r->pending = false; r->failed = rc; result_release(r); return rc; }
     }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, r->ev0, r->ev2)); r->st.ms_total = ms;
@@ -438,8 +450,9 @@ extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_
     pm_result* r = new pm_result();
     r->idx.assign(idx, idx + n_idx);
     r->q = q; r->threshold = threshold; r->nb_best = nb_best_hits; r->slot_base = slot_base;
-    const uint64_t want_cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, (uint64_t)q->headers.size() * 16),
-                                                 g_ctx.hit_hint + g_ctx.hit_hint / 4);
+    uint64_t hint;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); hint = g_ctx.hit_hint; }
+    const uint64_t want_cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, (uint64_t)q->headers.size() * 16), hint + hint / 4);
     int rc = enqueue_search(r, want_cap);
     if (rc) {
         // whatever was queued before the failure must not outlive its buffers
@@ -458,14 +471,20 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     int rc = pm_search_async(idx, n_idx, q, threshold, nb_best_hits, slot_base, &r);
     if (rc) return rc;
     rc = pm_result_wait(r);
-    if (rc) { delete r; return rc; }
+    if (rc) {                                   // nothing queued for this result may outlive its buffers or keep its workspace
+        (void)hipStreamSynchronize(g_ctx.stream);
+        r->pending = false;
+        result_release(r);
+        delete r;
+        return rc;
+    }
     *out = r;
     return PM_OK;
 }
 
 #define RESULT_READY(r)                                            \
     do {                                                           \
-        if ((r)->pending) {                                        \
+        if ((r)->pending || (r)->failed) {                         \
             int rc_w_ = pm_result_wait(const_cast<pm_result_t*>(r)); \
             if (rc_w_) return rc_w_;                               \
         }                                                          \
@@ -650,12 +669,23 @@ static int ensure_ordered(pm_result* r) {
     OCHK(hipMemcpyAsync(d_plan, h_plan, np * sizeof(uint4), hipMemcpyHostToDevice, st));
     OCHK(launch_permute_runs(d_plan, (uint32_t)np, r->d_hits, r->d_ord.p, st));
     OCHK(hipStreamSynchronize(st));
-    // groups merged from several runs: interleave by score on the host, write back
-    for (auto& f : r->fixups) {
-        std::vector<pm_hit_t> tmp((size_t)(f.second - f.first));
-        OCHK(hipMemcpy(tmp.data(), r->d_ord.p + f.first, tmp.size() * sizeof(pm_hit_t), hipMemcpyDeviceToHost));
-        std::sort(tmp.begin(), tmp.end(), hit_less);
-        OCHK(hipMemcpy(r->d_ord.p + f.first, tmp.data(), tmp.size() * sizeof(pm_hit_t), hipMemcpyHostToDevice));
+    // groups merged from several runs (rows wider than 1024 bytes, compact sub-indexes): the span that holds them
+    // travels to the host ONCE (pinned), every group is interleaved by score there, and the span goes back once --
+    // not a pair of blocking copies per group
+    if (!r->fixups.empty()) {
+        const uint64_t lo = r->fixups.front().first, hi = r->fixups.back().second;
+        PinBuf span{nullptr, 0};
+        { int rc = take_pinned((size_t)(hi - lo) * sizeof(pm_hit_t), &span); if (rc) return done(rc); }
+        pm_hit_t* hp = (pm_hit_t*)span.p;
+        hipError_t e = hipMemcpyAsync(hp, r->d_ord.p + lo, (size_t)(hi - lo) * sizeof(pm_hit_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) {
+            for (auto& f : r->fixups) std::sort(hp + (f.first - lo), hp + (f.second - lo), hit_less);
+            e = hipMemcpyAsync(r->d_ord.p + lo, hp, (size_t)(hi - lo) * sizeof(pm_hit_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        give_pinned(span);
+        if (e != hipSuccess) return done(fail(PM_EHIP, "ordering of multi-run groups: %s", hipGetErrorString(e)));
     }
 #undef OCHK
     r->ordered = true;

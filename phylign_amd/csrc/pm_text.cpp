@@ -201,6 +201,7 @@ struct MergeBatch {
     std::string name;                   // batch name of "<batch>____<qfile>.gz"
     std::string refs;                   // reference names, '\0' separated
     std::vector<uint32_t> ref_off;      // n_docs + 1
+    std::vector<uint32_t> ref_rank;     // position of the document's reference name in the batch's sorted names
 };
 struct pm_merge {
     const pm_queries* q = nullptr;
@@ -218,7 +219,11 @@ struct pm_merge {
     }
     bool less(const MergeItem& a, const MergeItem& b) const {       // (-kmers, batch, ref): scripts/filter_queries.py:135
         if (a.kmers != b.kmers) return a.kmers > b.kmers;
-        if (a.batch != b.batch) { const int c = batches[a.batch].name.compare(batches[b.batch].name); if (c) return c < 0; }
+        if (a.batch == b.batch) {                                   // the usual case: integer compare
+            const uint32_t ra = batches[a.batch].ref_rank[a.doc], rb = batches[a.batch].ref_rank[b.doc];
+            return ra != rb ? ra < rb : a.doc < b.doc;
+        }
+        { const int c = batches[a.batch].name.compare(batches[b.batch].name); if (c) return c < 0; }
         size_t la, lb;
         const char* ra = ref(a, &la); const char* rb = ref(b, &lb);
         const int c = memcmp(ra, rb, std::min(la, lb));
@@ -283,6 +288,20 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
         mb.refs.push_back('\0');
     }
     mb.ref_off[ix->info.n_docs] = (uint32_t)mb.refs.size();
+    {   // rank of every reference name inside the batch: ordering the items of one batch needs no string compare
+        std::vector<uint32_t> order((size_t)ix->info.n_docs);
+        for (uint32_t d = 0; d < ix->info.n_docs; ++d) order[d] = d;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const int c = strcmp(mb.refs.data() + mb.ref_off[x], mb.refs.data() + mb.ref_off[y]);
+            return c ? c < 0 : x < y;
+        });
+        mb.ref_rank.resize((size_t)ix->info.n_docs);
+        uint32_t r = 0;
+        for (size_t i = 0; i < order.size(); ++i) {
+            if (i && strcmp(mb.refs.data() + mb.ref_off[order[i]], mb.refs.data() + mb.ref_off[order[i - 1]]) != 0) r = (uint32_t)i;
+            mb.ref_rank[order[i]] = r;
+        }
+    }
     size_t p = 0;
     while (p < n_mine) {
         size_t e = p;
@@ -314,7 +333,10 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
             if (mine[i].score >= m->floor_[target]) v.push_back({mine[i].score, bid, mine[i].doc});
         }
         if (v.size() != before) {
-            std::sort(v.begin(), v.end(), [&](const MergeItem& a, const MergeItem& b) { return m->less(a, b); });
+            // the new items (one batch) are ordered among themselves, then merged into the kept ones
+            auto lt = [&](const MergeItem& a, const MergeItem& b) { return m->less(a, b); };
+            std::sort(v.begin() + (long)before, v.end(), lt);
+            if (before) std::inplace_merge(v.begin(), v.begin() + (long)before, v.end(), lt);
             if (v.size() > m->keep) {
                 if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
                 size_t cut = m->keep;

@@ -359,3 +359,83 @@ def test_resident_index_server_evicts_under_budget(pm, oracle, tmp_path):
         except Exception:
             srv.kill()
         srv.wait(timeout=30)
+
+
+def test_server_keeps_serving_during_a_cold_load_and_fuses_concurrent_jobs(pm, oracle, tmp_path):
+    """what 305 per-batch Snakemake jobs do to a resident-index server (Snakefile:431-487): requests arrive together.
+    A cold index (fed through a FIFO that stalls for 2 s) is loaded by its own handler thread; meanwhile three
+    clients with the same query file against three resident batches are answered at once -- by ONE fused search --,
+    a second client of the cold index waits for the same load instead of starting another, and every answer is
+    byte-identical to the oracle."""
+    import threading
+    import time
+    from phylign_amd.server import request
+    sock = str(tmp_path / "pm.sock")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    rng = np.random.default_rng(91)
+    queries = [(f"c{i}", rand_seq(rng, 150)) for i in range(40)]
+    cases = []
+    for b, (n_docs, S) in enumerate(((195, 30000), (664, 20000), (4000, 9000), (300, 25000))):
+        plant = [(qi, (qi * 13 + j) % n_docs, fr) for qi in range(40) for j, fr in enumerate((1.0, 0.9, 0.8, 0.7, 0.6))]
+        index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant)
+        p = tmp_path / f"res{b}__01.cobs_classic"
+        if b < 3:
+            p.write_bytes(bytes(index))
+        cases.append((str(p), bytes(index), oracle.query_file(index, fasta, 0.7)))
+    cold_path, cold_bytes, cold_text = cases[3]
+    os.mkfifo(cold_path)
+    srv = subprocess.Popen([sys.executable, "-m", "phylign_amd.server", "--socket", sock, "--coalesce-ms", "400"],
+                           env=env, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.1)
+        assert os.path.exists(sock), "server did not come up"
+        h, _ = request(sock, {"op": "preload", "indexes": [c[0] for c in cases[:3]], "wait": True})
+        assert h["ok"] and h["queued"] == 3
+        st, _ = request(sock, {"op": "stats"})
+        assert st["resident"] == 3 and st["loads"] == 3 and st["resident_bytes"] > 0
+
+        def feed():                                   # the slow decoder of the cold index
+            with open(cold_path, "wb") as f:
+                f.write(cold_bytes[: len(cold_bytes) // 2])
+                f.flush()
+                time.sleep(2.0)
+                f.write(cold_bytes[len(cold_bytes) // 2:])
+        out, lat = {}, {}
+
+        def client(name, path):
+            t0 = time.time()
+            out[name] = request(sock, {"op": "query", "index": path, "fasta_len": len(fasta), "threshold": 0.7}, fasta)
+            lat[name] = time.time() - t0
+        threads = [threading.Thread(target=feed), threading.Thread(target=client, args=("cold_a", cold_path))]
+        for t in threads:
+            t.start()
+        time.sleep(0.3)                               # the cold load is under way
+        more = [threading.Thread(target=client, args=("cold_b", cold_path))]
+        more += [threading.Thread(target=client, args=(f"res{b}", cases[b][0])) for b in range(3)]
+        for t in more:
+            t.start()
+        for t in threads + more:
+            t.join(timeout=120)
+        for b in range(3):
+            head, body = out[f"res{b}"]
+            assert head["ok"] and head["cached"] and body == cases[b][2], b
+            assert lat[f"res{b}"] < 1.5, lat               # answered while the cold index was still loading
+        for name in ("cold_a", "cold_b"):
+            head, body = out[name]
+            assert head["ok"] and body == cold_text
+            assert lat[name] > 1.5
+        st, _ = request(sock, {"op": "stats"})
+        assert st["loads"] == 4 and st["waited_for_a_load"] >= 1 and st["resident"] == 4
+        assert st["max_batches_in_one_search"] >= 3 and st["searches"] < st["jobs"] == 5
+    finally:
+        try:
+            request(sock, {"op": "shutdown"})
+        except Exception:
+            srv.kill()
+        try:
+            srv.wait(timeout=30)
+        except Exception:
+            srv.kill()

@@ -95,6 +95,24 @@ def test_mixed_lengths_and_plane_classes(pm, oracle):
     assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"3", "7", "10", "16", "20", "24"}
 
 
+def test_header_with_an_impossible_row_count_is_rejected_before_allocation(pm, oracle):
+    """a header whose signature_size makes rows x stride wrap around 2^64 (or just exceed HBM) is PM_EFORMAT:
+    nothing is allocated, nothing is uploaded next to other resident indexes"""
+    import struct
+    rng = np.random.default_rng(8)
+    index, _, _ = build_case(oracle, rng, 100, 777, [("a", rand_seq(rng, 50))])
+    raw = bytes(index)
+    at = raw.index(struct.pack("<Q", 777), 18, 80)
+    free0 = pm.device_info()["hbm_free"]
+    for sig in (1 << 61, (1 << 64) // 16 + 1, 1 << 40):
+        bad = raw[:at] + struct.pack("<Q", sig) + raw[at + 8:]
+        with pytest.raises(pm.PMError) as e:
+            pm.Index.load_mem(bad)
+        assert e.value.code == -5, e.value
+    assert pm.device_info()["hbm_free"] >= free0 - (64 << 20)
+    assert pm.Index.load_mem(raw).info.signature_size == 777
+
+
 def test_fasta_record_rules(pm, oracle):
     rng = np.random.default_rng(6)
     s = [rand_seq(rng, 90) for _ in range(4)]

@@ -31,6 +31,7 @@ import json
 import os
 import queue
 import socket
+import stat
 import subprocess
 import sys
 import threading
@@ -81,6 +82,8 @@ class IndexCache:
         """(Index, was_resident): the entry stays pinned until release(path_key)"""
         st = os.stat(path)
         key = (os.path.realpath(path), st.st_mtime_ns, st.st_size)
+        if not stat.S_ISREG(st.st_mode):               # a pipe: its times move while it is written
+            key = (os.path.realpath(path), 0, 0)
         loader = False
         with self.mu:
             e = self.items.get(key)

@@ -654,11 +654,16 @@ def main():
         fasta1m, _ = W.make_queries(1_000_000, args.qlen, seed=5)
         q1m = pm.Queries(fasta1m, term_size=31)
         del fasta1m
+        plan1m, sure1m = W.plant_plan(q1m.hash_terms(1, 1), 1_000_000, terms_per_q, fsub, every=2500, docs_per_query=8)
+        for i, ix in enumerate(indexes):
+            if i in plan1m:
+                ix.plant(*plan1m[i])
         cur.update({"q": q1m, "n_terms": 1_000_000 * terms_per_q, "tag": cur["tag"] + "/1M"})
-        full_shard["queries_1M"] = {"setup_s": round(time.time() - t0, 2)}
+        full_shard["queries_1M"] = {"setup_s": round(time.time() - t0, 2), "planted_pairs_at_or_above_threshold": sure1m}
         for m in modes:
             r = timed_run(m == "threshold_bound", 1, 2)
             sm = summary(r, 2, m, None)
+            ok = ok and sm["hits"] is not None and sm["hits"] >= sure1m
             full_shard["queries_1M"][m] = {"value": sm["value"], "unit": "k-mers/s", "ms_per_step": sm["ms_per_step"],
                                            "hits": sm["hits"], "roofline": sm["roofline"], "roofline_narrow": sm["roofline_narrow"]}
         cur.clear(); cur.update(saved)

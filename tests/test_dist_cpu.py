@@ -137,3 +137,26 @@ def test_loader_admission_is_in_submission_order_and_never_deadlocks():
             time.sleep(0.0005)
             adm.release(needs[t])
     assert order == sorted(order) and adm.resident == 0
+
+
+def test_eight_way_partition_of_config3_is_balanced_on_measured_batch_times():
+    """the static batch -> GPU map of bench.py --gpus 8 (workload.assign_batches on line-cost weights) priced with the
+    per-batch scan times MEASURED on one MI355X (profiles/r02/per_batch_cost.tsv): slowest rank / mean <= 1.05 in
+    both scan modes, for 2, 4 and 8 ranks -- the bound on strong-scaling efficiency that the partition itself costs"""
+    import os
+    from phylign_amd import workload as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cost = {}
+    with open(os.path.join(root, "profiles", "r02", "per_batch_cost.tsv")) as f:
+        head = f.readline().rstrip("\n").split("\t")
+        for line in f:
+            row = dict(zip(head, line.rstrip("\n").split("\t")))
+            cost[row["batch"]] = (float(row["ms_fetch_all"]), float(row["ms_bound"]))
+    shapes = W.select("config3")
+    assert len(shapes) == 64 and all(s.batch in cost for s in shapes)
+    for n in (2, 4, 8):
+        parts = W.assign_batches(shapes, n)
+        assert sorted(i for p in parts for i in p) == list(range(64))
+        for mode in (0, 1):
+            loads = [sum(cost[shapes[i].batch][mode] for i in p) for p in parts]
+            assert max(loads) / (sum(loads) / n) <= 1.05, (n, mode, loads)

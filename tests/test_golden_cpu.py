@@ -699,3 +699,22 @@ def test_cpu_baseline_partitions_agree_with_the_oracle_scores(oracle):
         assert O.baseline_run(m, h.row_bytes, h, seqs.tobytes(), qlen, nq, 0.2, 3) == want
         for slab in (16, 64, 1000):
             assert O.baseline_run_slabs(m, h.row_bytes, h, seqs.tobytes(), qlen, nq, 0.2, 3, slab) == want
+
+
+def test_native_fix_query_on_the_reference_bundled_inputs():
+    """the four query files `make test` feeds to rule fix_query (data/reads_1.fastq, reads_2.fq, reads_3.fasta,
+    reads_4.fa; Snakefile:308-352): the native parser turns each into its prepared form, and their concatenation is
+    the merged query file of the 03_match stage"""
+    from phylign_amd import _lib as pm
+    raw_dir = os.path.join(GOLD, "reads", "raw")
+    parts = []
+    for f in ("reads_1.fastq", "reads_2.fq", "reads_3.fasta", "reads_4.fa"):
+        raw = open(os.path.join(raw_dir, f), "rb").read()
+        q = pm.Queries(raw, term_size=31, normalise=True)
+        assert q.count()[0] == 10
+        parts.append(q.fasta())
+    merged = open(os.path.join(GOLD, "reads", "reads_1___reads_2___reads_3___reads_4.fa"), "rb").read()
+    assert b"".join(parts) == merged
+    # a FASTQ is not a prepared query file: without normalisation the cobs record rules make nonsense of it -> error
+    with pytest.raises(pm.PMError):
+        pm.Queries(open(os.path.join(raw_dir, "reads_1.fastq"), "rb").read(), term_size=31)

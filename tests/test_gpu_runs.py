@@ -235,6 +235,20 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     a, b = np.load(one), np.load(two)
     assert len(a) > 50 and np.array_equal(a, b)
+    line2 = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    part = line2["participants"]
+    assert part["ranks"] == 2 and len(part["rank_ms_per_step"]) == 2 and part["rank_devices"] == [0, 0]
+    assert sum(part["rank_batches"]) == 64 and min(part["rank_batches"]) >= 1
+    assert abs(max(part["rank_ms_per_step"]) - line2["ms_per_step"]) < 1e-6          # the job's step is the slowest rank's
+    # one rank under the launcher the driver uses = the plain invocation (same records, a bench line of the same shape)
+    solo = tmp_path / "solo.npy"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29548", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--no-clustered"] + common + ["--dump-hits", str(solo)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line1 = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert np.array_equal(np.load(solo), a) and line1["n_gpus"] == 1 and line1["hits"] == line["hits"]
+    assert line1["participants"]["rank_devices"] == [0] and line1["l31"]["config2"]["hit_records"] > 0
 
 
 def test_hit_buffer_overflow_reruns_with_the_exact_size(pm, oracle):

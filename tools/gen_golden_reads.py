@@ -15,3 +15,8 @@ files = [os.path.join(ref, "data", f) for f in ("reads_1.fastq", "reads_2.fq", "
 with open(os.path.join(out, "reads_1___reads_2___reads_3___reads_4.fa"), "wb") as f:
     fix_files(files, f)
 print(open(os.path.join(out, "reads_1___reads_2___reads_3___reads_4.fa")).read().count(">"), "reads")
+# the four input files themselves (FASTQ and FASTA, as `make test` feeds them to rule fix_query): data fixtures
+import shutil
+os.makedirs(os.path.join(out, "raw"), exist_ok=True)
+for f in files:
+    shutil.copyfile(f, os.path.join(out, "raw", os.path.basename(f)))

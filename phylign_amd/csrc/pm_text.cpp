@@ -334,8 +334,14 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
         }
         if (v.size() != before) {
             // the new items (one batch) are ordered among themselves, then merged into the kept ones
+            // (they arrive best score first, ties by document: only runs of equal scores need re-ordering by name)
             auto lt = [&](const MergeItem& a, const MergeItem& b) { return m->less(a, b); };
-            std::sort(v.begin() + (long)before, v.end(), lt);
+            for (size_t a0 = before; a0 < v.size();) {
+                size_t a1 = a0 + 1;
+                while (a1 < v.size() && v[a1].kmers == v[a0].kmers) ++a1;
+                if (a1 - a0 > 1) std::sort(v.begin() + (long)a0, v.begin() + (long)a1, lt);
+                a0 = a1;
+            }
             if (before) std::inplace_merge(v.begin(), v.begin() + (long)before, v.end(), lt);
             if (v.size() > m->keep) {
                 if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");

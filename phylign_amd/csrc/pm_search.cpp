@@ -452,7 +452,13 @@ extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_
     r->q = q; r->threshold = threshold; r->nb_best = nb_best_hits; r->slot_base = slot_base;
     uint64_t hint;
     { std::lock_guard<std::mutex> lk(g_pool_mu); hint = g_ctx.hit_hint; }
-    const uint64_t want_cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, (uint64_t)q->headers.size() * 16), hint + hint / 4);
+    // first guess of the record count: 48 per query (a read that matches its species' batch brings ~100 records after the
+    // n-best cut; most reads match nothing elsewhere), at most 1/32 of the free HBM; a search that needs more is queued
+    // again with the exact size (pm_result_wait) and later searches start from what was seen
+    size_t fr = 0, tot = 0;
+    (void)hipMemGetInfo(&fr, &tot);
+    const uint64_t per_query = std::min<uint64_t>((uint64_t)q->headers.size() * 48, (uint64_t)fr / 32 / sizeof(uint4) / 2);
+    const uint64_t want_cap = std::max<uint64_t>(std::max<uint64_t>(1u << 20, std::max<uint64_t>(per_query, (uint64_t)q->headers.size() * 16)), hint + hint / 4);
     int rc = enqueue_search(r, want_cap);
     if (rc) {
         // whatever was queued before the failure must not outlive its buffers

@@ -251,13 +251,15 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             tb = time.perf_counter()
             # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
             pgzip.write(os.path.join(out_dir, f"{b}____{qfile}.gz"), text, level=1, pool=deflaters)
-            tc = time.perf_counter()
+            tc = tc0 = time.perf_counter()
+            td = tc
             if merge is not None:
                 with merge_mu:                           # the library serialises adds anyway; the ordinal of the add is the export's slot
+                    tc = time.perf_counter()             # (time spent waiting for the lock is not merge work)
                     merge.add(b, ix, part, slot=i, nb_best_hits=nb)
                     merge_order.append(b)
-            td = time.perf_counter()
-            add_time("format_s", tb - ta); add_time("gzip_s", tc - tb); add_time("merge_s", td - tc)
+                    td = time.perf_counter()
+            add_time("format_s", tb - ta); add_time("gzip_s", (tc if merge is None else tc0) - tb); add_time("merge_s", td - tc)
             if keep_texts is not None:
                 keep_texts[b] = text
             return len(part)

@@ -21,7 +21,7 @@ for s in shapes:
             best = min(best, r.stats.ms_scan)
             r.free()
         out.append(best)
-    lines = W.scan_cost(s) // 128
+    lines = (s.row_bytes + 127) // 128
     print(f"{s.batch}\t{s.n_docs}\t{s.row_bytes}\t{info.stride}\t{s.signature_size}\t{info.device_bytes / 1e9:.2f}\t{lines}\t"
           f"{out[0]:.3f}\t{out[1]:.3f}\t{out[0] * 1e6 / (12e6 * lines):.3f}")
     ix.free()

@@ -281,6 +281,9 @@ int  pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* idx,
 int  pm_merge_export(const pm_merge_t* m, pm_hit_t** hits, uint64_t* n);
 /* ">qname ref1,ref2,...\nseq\n" per query in FASTA order; *text malloc'd, pm_free() */
 int  pm_merge_emit(const pm_merge_t* m, char** text, size_t* len);
+/* the same text written to `path` (via "<path>.tmp" + rename), built and written on several threads;
+ * *bytes (optional) = size of the file */
+int  pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes);
 void pm_merge_free(pm_merge_t* m);
 
 #ifdef __cplusplus

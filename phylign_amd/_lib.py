@@ -100,6 +100,7 @@ SYMBOLS = [
     ("pm_merge_add", C.c_int, [_P, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
     ("pm_merge_export", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pm_merge_emit_file", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
     ("pm_merge_free", None, [_P]),
     ("pm_query_text", C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_double, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
 ]
@@ -422,6 +423,12 @@ class Merge:
         out = np.frombuffer(buf, dtype=HIT_DTYPE).copy()
         load().pm_free(p)
         return out
+
+    def emit_to(self, path) -> int:
+        """writes the 04_filter FASTA to `path` (atomically); returns its size"""
+        n = C.c_uint64()
+        _chk(load().pm_merge_emit_file(self._h, os.fsencode(path), C.byref(n)))
+        return n.value
 
     def emit(self) -> bytes:
         t, n = _P(), C.c_size_t()

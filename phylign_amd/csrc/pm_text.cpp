@@ -377,32 +377,101 @@ extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n
     return PM_OK;
 }
 
-extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
-    if (!m || !text || !len) return fail(PM_EINVAL, "bad argument");
-    std::string out;
+// The FASTA text in `nt` consecutive pieces, built on `nt` threads (query ranges are independent).
+static void merge_emit_pieces(const pm_merge* m, std::vector<std::string>& parts) {
     const pm_queries* q = m->q;
     // dict semantics of the consumer: one record per distinct name, at the position of its
     // first occurrence, with the sequence of its last occurrence
-    std::vector<char> seen(q->headers.size(), 0);
-    for (size_t i = 0; i < q->headers.size(); ++i) {
-        const uint32_t rec = m->by_name.at(m->qnames[i]);
-        if (seen[rec]) continue;
-        seen[rec] = 1;
-        out.push_back('>'); out += m->qnames[i]; out.push_back(' ');
-        const std::vector<MergeItem>& v = m->items[rec];
-        for (size_t k = 0; k < v.size(); ++k) {
-            if (k) out.push_back(',');
-            size_t rl; const char* r = m->ref(v[k], &rl);
-            out.append(r, rl);
+    std::vector<uint32_t> recs;
+    recs.reserve(q->headers.size());
+    {
+        std::vector<char> seen(q->headers.size(), 0);
+        for (size_t i = 0; i < q->headers.size(); ++i) {
+            const uint32_t rec = m->by_name.at(m->qnames[i]);
+            if (seen[rec]) continue;
+            seen[rec] = 1;
+            recs.push_back(rec);
         }
-        out.push_back('\n');
-        out.append(q->seqs, (size_t)q->seq_off[rec], (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]));
-        out.push_back('\n');
     }
-    char* buf = (char*)malloc(out.size() + 1);
+    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), recs.size() / 8192);
+    if (nt < 1) nt = 1;
+    parts.assign(nt, std::string());
+    auto work = [&](size_t t) {
+        std::string& out = parts[t];
+        const size_t a = recs.size() * t / nt, b = recs.size() * (t + 1) / nt;
+        size_t guess = 0;
+        for (size_t k = a; k < b; ++k)
+            guess += m->qnames[recs[k]].size() + 4 + (size_t)(q->seq_off[recs[k] + 1] - q->seq_off[recs[k]]) + m->items[recs[k]].size() * 16;
+        out.reserve(guess);
+        for (size_t k = a; k < b; ++k) {
+            const uint32_t rec = recs[k];
+            out.push_back('>'); out += m->qnames[rec]; out.push_back(' ');
+            const std::vector<MergeItem>& v = m->items[rec];
+            for (size_t j = 0; j < v.size(); ++j) {
+                if (j) out.push_back(',');
+                size_t rl; const char* r = m->ref(v[j], &rl);
+                out.append(r, rl);
+            }
+            out.push_back('\n');
+            out.append(q->seqs, (size_t)q->seq_off[rec], (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]));
+            out.push_back('\n');
+        }
+    };
+    if (nt == 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
+
+extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
+    if (!m || !text || !len) return fail(PM_EINVAL, "bad argument");
+    std::vector<std::string> parts;
+    merge_emit_pieces(m, parts);
+    size_t total = 0;
+    for (auto& s2 : parts) total += s2.size();
+    char* buf = (char*)malloc(total + 1);
     if (!buf) return fail(PM_ENOMEM, "out of host memory");
-    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
-    *text = buf; *len = out.size();
+    size_t o = 0;
+    for (auto& s2 : parts) { memcpy(buf + o, s2.data(), s2.size()); o += s2.size(); }
+    buf[total] = 0;
+    *text = buf; *len = total;
+    return PM_OK;
+}
+
+// The same text written to `path` (through "<path>.tmp" + rename: never a partial file that looks
+// complete), the pieces written in parallel at their offsets: the 04_filter FASTA of a million reads
+// is hundreds of MB that need not pass through the caller.
+extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes) {
+    if (!m || !path) return fail(PM_EINVAL, "bad argument");
+    std::vector<std::string> parts;
+    merge_emit_pieces(m, parts);
+    const std::string tmp = std::string(path) + ".tmp";
+    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(PM_EIO, "cannot create '%s': %s", tmp.c_str(), strerror(errno));
+    std::vector<uint64_t> off(parts.size() + 1, 0);
+    for (size_t t = 0; t < parts.size(); ++t) off[t + 1] = off[t] + parts[t].size();
+    std::vector<int> errs(parts.size(), 0);
+    auto wr = [&](size_t t) {
+        const char* p = parts[t].data(); size_t left = parts[t].size(); uint64_t o = off[t];
+        while (left) {
+            ssize_t w = pwrite(fd, p, left, (off_t)o);
+            if (w < 0) { if (errno == EINTR) continue; errs[t] = errno; return; }
+            p += w; left -= (size_t)w; o += (uint64_t)w;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < parts.size(); ++t) th.emplace_back(wr, t);
+        wr(0);
+        for (auto& x : th) x.join();
+    }
+    int e = 0;
+    for (int x : errs) if (x) e = x;
+    if (close(fd) != 0 && !e) e = errno;
+    if (e) { (void)unlink(tmp.c_str()); return fail(PM_EIO, "writing '%s': %s", tmp.c_str(), strerror(e)); }
+    if (rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
+    if (bytes) *bytes = off.back();
     return PM_OK;
 }
 

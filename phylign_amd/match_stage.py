@@ -418,10 +418,7 @@ def main(argv=None):
                             nix.free()
         if rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
-            tmp = args.filter_out + ".tmp"
-            with open(tmp, "wb") as f:
-                f.write(merge.emit())
-            os.replace(tmp, args.filter_out)
+            report["filter_fasta_bytes"] = merge.emit_to(args.filter_out)
     report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
     if world > 1:
         dist.barrier()

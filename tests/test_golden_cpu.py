@@ -306,6 +306,11 @@ def test_native_merge_matches_reference_filter_fixture(keep):
         ix = pm.Index.from_names(list(names) or ["x_y"])
         m.add(b, ix, np.array(recs, dtype=pm.HIT_DTYPE), slot=7, nb_best_hits=-1)
     assert m.emit().decode() == open(os.path.join(d, f"expected.n{keep}.fa")).read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:                    # the threaded, straight-to-file form writes the same bytes
+        n = m.emit_to(os.path.join(td, "out.fa"))
+        assert open(os.path.join(td, "out.fa"), "rb").read() == m.emit() and n == len(m.emit())
+        assert os.listdir(td) == ["out.fa"]
 
 
 def _filter_fixture_batches(pm):

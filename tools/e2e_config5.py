@@ -79,10 +79,8 @@ def main():
             report, merge = MS.run_stage(pm, names, list(range(len(names))), src, q, "Q", out_dir, args.threshold,
                                          args.nb_best_hits, want_merge=True, max_group=mg)
             t1 = time.perf_counter()
-            text = merge.emit()
             os.makedirs(os.path.join(args.out, "04_filter"), exist_ok=True)
-            with open(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"), "wb") as f:
-                f.write(text)
+            fasta_bytes = merge.emit_to(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
             t2 = time.perf_counter()
             merge.free()
             if warm and args.queries > 200_000:
@@ -105,7 +103,7 @@ def main():
             "e2e_s": round(t_parse + (t2 - t0), 3),
             "e2e_kmers_per_s": n_terms / (t_parse + (t2 - t0)),
             "records": sum(g["records"] for g in report["per_group"]),
-            "gz_bytes": gz, "filter_fasta_bytes": len(text), "host_cpus": len(os.sched_getaffinity(0)),
+            "gz_bytes": gz, "filter_fasta_bytes": fasta_bytes, "host_cpus": len(os.sched_getaffinity(0)),
         }
         print(json.dumps(line), flush=True)
 

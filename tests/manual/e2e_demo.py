@@ -54,8 +54,9 @@ r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--batches"
 wall = time.time() - t0
 assert r.returncode == 0, r.stderr.decode()[-2000:]
 log = json.loads(r.stderr.decode().strip().split("\n")[-1])
-print(f"match_stage: {N} reads x {len(shapes)} batches, process wall {wall:.2f}s (stage wall {log['wall_s']}s)")
-for row in log["per_batch"]:
+print(f"match_stage: {N} reads x {len(shapes)} batches, process wall {wall:.2f}s (stage wall {log['stage_wall_s']}s, "
+      f"match only {log['match_only_s']}s, e2e {log['e2e_s']}s)")
+for row in log["per_group"]:
     print("  ", row)
 b0 = shapes[0].batch
 nq = 300

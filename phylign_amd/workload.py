@@ -47,10 +47,10 @@ def scale_shapes(shapes, rows_divisor):
                        index_bytes=max(1024, s.signature_size // rows_divisor) * s.row_bytes) for s in shapes]
 
 
-# measured scan time per looked-up row by 128-byte lines per row, relative to one line of a 4-line row
-# (tools/per_batch_cost.py on one MI355X, 12 M lookups per batch, fetch-all scan; profiles/r02/per_batch_cost.tsv):
-# 0.28 / 0.54 / 0.84 / 1.03 ms for 1 / 2 / 3 / 4 lines
-_LINE_COST = {1: 109, 2: 210, 3: 327, 4: 400}
+# measured scan time per looked-up row by 128-byte lines per row, relative to 400 for a 4-line row
+# (tools/per_batch_cost.py on one MI355X, 12 M lookups per batch, fetch-all scan with non-temporal gathers;
+# profiles/r03/per_batch_cost.tsv): 0.281 / 0.511 / 0.726 / 0.966 ms for 1 / 2 / 3 / 4 lines
+_LINE_COST = {1: 116, 2: 212, 3: 301, 4: 400}
 
 
 def scan_cost(shape):

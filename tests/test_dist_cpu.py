@@ -141,13 +141,13 @@ def test_loader_admission_is_in_submission_order_and_never_deadlocks():
 
 def test_eight_way_partition_of_config3_is_balanced_on_measured_batch_times():
     """the static batch -> GPU map of bench.py --gpus 8 (workload.assign_batches on line-cost weights) priced with the
-    per-batch scan times MEASURED on one MI355X (profiles/r02/per_batch_cost.tsv): slowest rank / mean <= 1.05 in
+    per-batch scan times MEASURED on one MI355X (profiles/r03/per_batch_cost.tsv): slowest rank / mean <= 1.05 in
     both scan modes, for 2, 4 and 8 ranks -- the bound on strong-scaling efficiency that the partition itself costs"""
     import os
     from phylign_amd import workload as W
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cost = {}
-    with open(os.path.join(root, "profiles", "r02", "per_batch_cost.tsv")) as f:
+    with open(os.path.join(root, "profiles", "r03", "per_batch_cost.tsv")) as f:
         head = f.readline().rstrip("\n").split("\t")
         for line in f:
             row = dict(zip(head, line.rstrip("\n").split("\t")))

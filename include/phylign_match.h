@@ -272,6 +272,13 @@ int  pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out);
  * from several threads (serialised inside). */
 int  pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* idx,
                   const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits);
+/* adds the 03_match TEXT of one batch (the content of "<batch>____<qfile>.gz" after gunzip) -- the native
+ * form of the reader of scripts/filter_queries.py:27-66 behind the drop-in scripts/filter_queries.py:
+ * "*<qname>[ comment]\t<N>" starts a query, every other non-empty line is "<rnd>_<ref> <kmers>" (two fields,
+ * exactly one '_'); a malformed line, a text without header and a query that is not in the query file fail
+ * with PM_EINVAL like the reference raises (match lines ahead of the first header join the first query, as
+ * they do there). */
+int  pm_merge_add_text(pm_merge_t* m, const char* batch, const char* text, size_t len);
 /* What the merge holds so far, as hit records {query, doc, score, slot = ordinal of the pm_merge_add
  * call that brought the batch} ordered by (slot, query, score desc, doc asc): one rank's share of the
  * 04_filter result.  The ranks of a multi-GPU stage gather these (the single RCCL gather at the end)

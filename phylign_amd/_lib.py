@@ -98,6 +98,7 @@ SYMBOLS = [
     ("pm_format_hits_limit", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     ("pm_merge_add", C.c_int, [_P, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
+    ("pm_merge_add_text", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("pm_merge_export", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_emit_file", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
@@ -414,6 +415,10 @@ class Merge:
     def add(self, batch: str, index: Index, hits, slot=0, nb_best_hits=-1):
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
         _chk(load().pm_merge_add(self._h, batch.encode(), index._h, hits.ctypes.data, hits.size, slot, nb_best_hits))
+
+    def add_text(self, batch: str, text: bytes):
+        """the 03_match text of one batch (after gunzip), as scripts/filter_queries.py reads it"""
+        _chk(load().pm_merge_add_text(self._h, batch.encode(), text, len(text)))
 
     def export(self):
         """what is kept so far as a HIT_DTYPE array (slot = ordinal of the add() call that brought the batch)"""

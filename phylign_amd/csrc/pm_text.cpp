@@ -233,6 +233,34 @@ struct pm_merge {
     }
 };
 
+// items [before, end) of query `target` are new (one batch): order them, merge them into the kept ones,
+// cut to the `keep` best + ties (scripts/filter_queries.py:133-150).  presorted: they arrive best score
+// first (records from a search), so only runs of equal scores need ordering by name.
+static int merge_settle(pm_merge* m, uint32_t target, size_t before, bool presorted) {
+    std::vector<MergeItem>& v = m->items[target];
+    auto lt = [&](const MergeItem& a, const MergeItem& b) { return m->less(a, b); };
+    if (v.size() != before) {
+        if (!presorted) std::sort(v.begin() + (long)before, v.end(), lt);
+        else
+            for (size_t a0 = before; a0 < v.size();) {
+                size_t a1 = a0 + 1;
+                while (a1 < v.size() && v[a1].kmers == v[a0].kmers) ++a1;
+                if (a1 - a0 > 1) std::sort(v.begin() + (long)a0, v.begin() + (long)a1, lt);
+                a0 = a1;
+            }
+        if (before) std::inplace_merge(v.begin(), v.begin() + (long)before, v.end(), lt);
+    }
+    if (v.size() > m->keep) {
+        if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
+        size_t cut = m->keep;
+        m->floor_[target] = v[cut - 1].kmers;
+        while (cut < v.size() && v[cut].kmers == m->floor_[target]) ++cut;
+        v.resize(cut);
+        v.shrink_to_fit();
+    }
+    return PM_OK;
+}
+
 extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
     if (!q || !out) return fail(PM_EINVAL, "bad argument");
     pm_merge* m = new pm_merge();
@@ -332,27 +360,101 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
             }
             if (mine[i].score >= m->floor_[target]) v.push_back({mine[i].score, bid, mine[i].doc});
         }
-        if (v.size() != before) {
-            // the new items (one batch) are ordered among themselves, then merged into the kept ones
-            // (they arrive best score first, ties by document: only runs of equal scores need re-ordering by name)
-            auto lt = [&](const MergeItem& a, const MergeItem& b) { return m->less(a, b); };
-            for (size_t a0 = before; a0 < v.size();) {
-                size_t a1 = a0 + 1;
-                while (a1 < v.size() && v[a1].kmers == v[a0].kmers) ++a1;
-                if (a1 - a0 > 1) std::sort(v.begin() + (long)a0, v.begin() + (long)a1, lt);
-                a0 = a1;
-            }
-            if (before) std::inplace_merge(v.begin(), v.begin() + (long)before, v.end(), lt);
-            if (v.size() > m->keep) {
-                if (m->keep == 0) return fail(PM_EINVAL, "keep = 0 is not supported by the 04_filter rule");
-                size_t cut = m->keep;
-                m->floor_[target] = v[cut - 1].kmers;
-                while (cut < v.size() && v[cut].kmers == m->floor_[target]) ++cut;
-                v.resize(cut);
-                v.shrink_to_fit();
-            }
-        }
+        { int rc = merge_settle(m, target, before, true); if (rc) return rc; }
         p = e;
+    }
+    return PM_OK;
+}
+
+// The 03_match TEXT of one batch (what `... | postprocess_cobs.py | gzip` wrote, after gunzip) added to the
+// merge: the native form of the consumer's reader (scripts/filter_queries.py:27-66) for the drop-in
+// scripts/filter_queries.py.  Rules kept: lines are stripped, empty ones skipped; "*<qname>[ comment]\t<N>"
+// starts a query (N must be an integer); any other line is "<rnd>_<ref> <kmers>" -- exactly two
+// whitespace-separated fields, exactly one '_' in the first; a text without any header and a query that is not
+// in the query file are errors, as they are in the reference (behaviour on odd input captured from the
+// reference's script: tests/golden/filter/edge/).
+extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* text, size_t len) {
+    if (!m || !batch || (!text && len)) return fail(PM_EINVAL, "bad argument");
+    struct Rec { uint32_t target, doc, kmers; };
+    std::vector<Rec> recs;
+    std::vector<std::pair<uint32_t, size_t>> blocks;               // (target query, first record) per '*' header
+    std::map<std::string, uint32_t> ref_id;
+    std::vector<std::string> refs;
+    auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+    auto parse_int = [](const char* b, const char* e, uint64_t* out) {
+        if (b < e && (*b == '+' || *b == '-')) ++b;      // int() takes a sign; the count of a header is never used
+        if (b >= e) return false;
+        uint64_t v = 0;
+        for (; b < e; ++b) { if (*b < '0' || *b > '9') return false; v = v * 10 + (uint64_t)(*b - '0'); if (v > 0xFFFFFFFFull) return false; }
+        *out = v;
+        return true;
+    };
+    size_t p = 0, lineno = 0;
+    bool have_header = false;
+    while (p < len) {
+        const char* nl = (const char*)memchr(text + p, '\n', len - p);
+        const char* b = text + p;
+        const char* e = nl ? nl : text + len;
+        p = (size_t)(e - text) + (nl ? 1 : 0);
+        ++lineno;
+        while (b < e && is_ws(*b)) ++b;
+        while (e > b && is_ws(e[-1])) --e;
+        if (b == e) continue;
+        if (*b == '*') {
+            const char* tab = (const char*)memchr(b + 1, '\t', (size_t)(e - (b + 1)));
+            uint64_t n = 0;
+            const char* nb = tab ? tab + 1 : e;
+            const char* ne = tab ? (const char*)memchr(nb, '\t', (size_t)(e - nb)) : nullptr;
+            if (!tab || !parse_int(nb, ne ? ne : e, &n))
+                return fail(PM_EINVAL, "batch %s line %zu: query header without an integer match count", batch, lineno);
+            const char* qe = (const char*)memchr(b + 1, ' ', (size_t)(tab - (b + 1)));
+            const std::string qname(b + 1, (size_t)((qe ? qe : tab) - (b + 1)));
+            auto it = m->by_name.find(qname);
+            if (it == m->by_name.end()) return fail(PM_EINVAL, "query '%s' of batch %s is not in the query file", qname.c_str(), batch);
+            // match lines ahead of the first header join the first query's list: the reference's reader only empties
+            // its buffer when it has a query to yield (scripts/filter_queries.py:52-56; pinned by a captured fixture)
+            blocks.push_back({it->second, have_header ? recs.size() : 0});
+            have_header = true;
+            continue;
+        }
+        const char* f1e = b;
+        while (f1e < e && !is_ws(*f1e)) ++f1e;
+        const char* f2b = f1e;
+        while (f2b < e && is_ws(*f2b)) ++f2b;
+        const char* f2e = f2b;
+        while (f2e < e && !is_ws(*f2e)) ++f2e;
+        uint64_t km = 0;
+        if (f2b == f2e || f2e != e || !parse_int(f2b, f2e, &km))
+            return fail(PM_EINVAL, "batch %s line %zu: a match line must be '<name> <k-mers>'", batch, lineno);
+        const char* us = (const char*)memchr(b, '_', (size_t)(f1e - b));
+        if (!us || memchr(us + 1, '_', (size_t)(f1e - (us + 1))))
+            return fail(PM_EINVAL, "batch %s line %zu: document name '%.*s' must hold exactly one '_' (scripts/filter_queries.py:64)",
+                        batch, lineno, (int)(f1e - b), b);
+        std::string ref(us + 1, (size_t)(f1e - (us + 1)));
+        auto ins = ref_id.emplace(std::move(ref), (uint32_t)refs.size());
+        if (ins.second) refs.push_back(ins.first->first);
+        recs.push_back({0u, ins.first->second, (uint32_t)km});
+    }
+    if (!have_header) return fail(PM_EINVAL, "batch %s: no '*' query header in the match text", batch);
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint32_t bid = (uint32_t)m->batches.size();
+    m->batches.emplace_back();
+    MergeBatch& mb = m->batches.back();
+    mb.name = batch;
+    mb.ref_off.resize(refs.size() + 1);
+    mb.ref_rank.resize(refs.size());
+    for (size_t d = 0; d < refs.size(); ++d) { mb.ref_off[d] = (uint32_t)mb.refs.size(); mb.refs += refs[d]; mb.refs.push_back('\0'); }
+    mb.ref_off[refs.size()] = (uint32_t)mb.refs.size();
+    { uint32_t r = 0; for (auto& kv : ref_id) mb.ref_rank[kv.second] = r++; }          // std::map iterates in name order
+    for (size_t k = 0; k < blocks.size(); ++k) {
+        const uint32_t target = blocks[k].first;
+        const size_t a = blocks[k].second, b2 = k + 1 < blocks.size() ? blocks[k + 1].second : recs.size();
+        std::vector<MergeItem>& v = m->items[target];
+        const size_t before = v.size();
+        for (size_t i = a; i < b2; ++i)
+            if (recs[i].kmers >= m->floor_[target]) v.push_back({recs[i].kmers, bid, recs[i].doc});
+        int rc = merge_settle(m, target, before, false);
+        if (rc) return rc;
     }
     return PM_OK;
 }

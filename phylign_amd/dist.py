@@ -70,6 +70,10 @@ class PackedGather:
         if self.rank != 0:
             if count > self.cap:
                 dist.send(overflow.contiguous(), 0, group=self.group)
+            if self.pack.is_cuda:
+                # with RCCL the collective is only QUEUED when dist.gather returns: the next step refills
+                # `pack` from another stream, so the send must have left the buffer first
+                torch.cuda.current_stream(self.pack.device).synchronize()
             return None
         counts = torch.stack([r[0, 0] for r in self.recv]).cpu().tolist()
         parts = []

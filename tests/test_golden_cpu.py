@@ -723,3 +723,115 @@ def test_native_fix_query_on_the_reference_bundled_inputs():
     # a FASTQ is not a prepared query file: without normalisation the cobs record rules make nonsense of it -> error
     with pytest.raises(pm.PMError):
         pm.Queries(open(os.path.join(raw_dir, "reads_1.fastq"), "rb").read(), term_size=31)
+
+
+# ------------------------------------------------ native reader of 03_match text (drop-in scripts/filter_queries.py)
+@pytest.mark.parametrize("keep", [1, 2, 5, 100])
+def test_native_merge_reads_match_text_like_the_reference_filter(keep):
+    """pm_merge_add_text on the gunzipped fixture files = the output captured from the reference's filter_queries.py"""
+    import gzip
+    from phylign_amd import _lib as pm
+    d = os.path.join(GOLD, "filter")
+    q = pm.Queries(open(os.path.join(d, "queries.fa"), "rb").read(), term_size=1)
+    m = pm.Merge(q, keep)
+    for b in ("aaa_bbb__01", "ccc_ddd__01", "ccc_ddd__02"):
+        m.add_text(b, gzip.open(os.path.join(d, f"{b}____q.gz"), "rb").read())
+    assert m.emit().decode() == open(os.path.join(d, f"expected.n{keep}.fa")).read()
+
+
+def test_filter_queries_drop_in_script_native_and_python(tmp_path):
+    """scripts/filter_queries.py with the reference's argv: native reader and --python reader give the fixture"""
+    d = os.path.join(GOLD, "filter")
+    files = [os.path.join(d, f"{b}____q.gz") for b in ("aaa_bbb__01", "ccc_ddd__01", "ccc_ddd__02")]
+    want = open(os.path.join(d, "expected.n2.fa"), "rb").read()
+    for extra in ([], ["--python"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "filter_queries.py"), "-n", "2", "-q",
+                            os.path.join(d, "queries.fa")] + files + extra, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == want and r.stderr.count(b"Translating matches") == 3
+
+
+def test_native_match_text_reader_random_against_the_python_mirror(tmp_path):
+    """random 03_match files (ties, comments in headers, blank lines, CRLF, shared references across batches): the
+    native reader and the golden-pinned Python mirror write the same FASTA"""
+    import gzip
+    from phylign_amd import _lib as pm
+    from phylign_amd import filter_queries as F
+    rng = np.random.default_rng(17)
+    nq = 300
+    qnames = [f"read{i}" for i in range(nq)]
+    fa = "".join(f">{n} comment {i}\n{''.join('ACGT'[j] for j in rng.integers(0, 4, 40))}\n" for i, n in enumerate(qnames))
+    (tmp_path / "q.fa").write_text(fa)
+    paths = []
+    for b in range(7):
+        lines = []
+        for i in rng.permutation(nq)[: int(rng.integers(50, nq))]:
+            k = int(rng.integers(0, 9))
+            lines.append(f"*{qnames[i]} c{i}\t{k}" + ("\r" if i % 11 == 0 else ""))
+            for _ in range(k):
+                lines.append(f"{rng.integers(0, 16**5):05x}_SAM{rng.integers(0, 40):03d}\t{rng.integers(20, 30)}")
+            if i % 7 == 0:
+                lines.append("")
+        p = tmp_path / f"genus_sp{b % 3}__{b:02d}____q.gz"
+        with gzip.open(p, "wt") as f:
+            f.write("\n".join(lines) + "\n")
+        paths.append(str(p))
+    for keep in (1, 3, 100):
+        out = io.StringIO()
+        F.filter_files(str(tmp_path / "q.fa"), paths, keep, out)
+        got = io.BytesIO()
+        assert F.filter_files_native(str(tmp_path / "q.fa"), paths, keep, got)
+        assert got.getvalue().decode() == out.getvalue()
+
+
+@pytest.mark.parametrize("text,needle", [
+    (b"xx_A\t5\n*r1\t1\n", b"before any"),
+    (b"", b"no '*' query header"),
+    (b"*r1\tabc\n", b"integer match count"),
+    (b"*r1\n", b"integer match count"),
+    (b"*nobody\t0\n", b"not in the query file"),
+    (b"*r1\t1\nxx_A_B\t5\n", b"exactly one '_'"),
+    (b"*r1\t1\nxxA\t5\n", b"exactly one '_'"),
+    (b"*r1\t1\nxx_A 5 6\n", b"'<name> <k-mers>'"),
+    (b"*r1\t1\nxx_A\tfive\n", b"'<name> <k-mers>'"),
+])
+def test_native_match_text_reader_fails_where_the_reference_raises(text, needle):
+    from phylign_amd import _lib as pm
+    q = pm.Queries(b">r1\nACGT\n", term_size=1)
+    m = pm.Merge(q, 5)
+    with pytest.raises(pm.PMError) as e:
+        m.add_text("b__01", text)
+    assert needle in str(e.value).encode()
+
+
+def _edge_cases():
+    d = os.path.join(GOLD, "filter", "edge")
+    return sorted(f[: -len("____q.txt")] for f in os.listdir(d) if f.endswith("____q.txt"))
+
+
+@pytest.mark.parametrize("case", _edge_cases())
+def test_filter_readers_on_edge_cases_captured_from_the_reference(case):
+    """match files with odd content run through the reference's filter_queries.py (tools/gen_golden_filter_edge.py):
+    where it printed a FASTA, the native reader and the Python mirror print the same; where it raised, both fail"""
+    from phylign_amd import _lib as pm
+    from phylign_amd import filter_queries as F
+    d = os.path.join(GOLD, "filter")
+    path = os.path.join(d, "edge", f"{case}____q.txt")
+    want_path = os.path.join(d, "edge", f"{case}.n3.fa")
+    qfa = os.path.join(d, "queries.fa")
+    q = pm.Queries(open(qfa, "rb").read(), term_size=1)
+    m = pm.Merge(q, 3)
+    text = open(path, "rb").read()
+    if os.path.exists(want_path):
+        want = open(want_path, "rb").read()
+        m.add_text(case, text)
+        assert m.emit() == want
+        out = io.StringIO()
+        F.filter_files(qfa, [path], 3, out)
+        assert out.getvalue().encode() == want
+    else:
+        assert os.path.exists(os.path.join(d, "edge", f"{case}.crash"))
+        with pytest.raises(pm.PMError):
+            m.add_text(case, text)
+        with pytest.raises(Exception):
+            F.filter_files(qfa, [path], 3, io.StringIO())

@@ -785,7 +785,7 @@ def test_native_match_text_reader_random_against_the_python_mirror(tmp_path):
 
 
 @pytest.mark.parametrize("text,needle", [
-    (b"xx_A\t5\n*r1\t1\n", b"before any"),
+    (b"xx_A\t5\n", b"no '*' query header"),
     (b"", b"no '*' query header"),
     (b"*r1\tabc\n", b"integer match count"),
     (b"*r1\n", b"integer match count"),

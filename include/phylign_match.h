@@ -121,6 +121,8 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * "wide_query" (default 0 = automatic): query classes of 128+ k-mers with too few queries
  * to fill the GPU are scanned with several lane groups per query (partial counts added
  * through LDS; the threshold bound is off in that form); 1 = always, 2 = never.
+ * "wide_query_split" (default 0 = automatic): in that form, how many workgroups share the steps of one query
+ * (a dozen chromosome-sized queries would otherwise leave most of the chip idle); 1 = never, n = force n.
  * "single_launch" (default 0): rows of every width up to 1024 B share one launch. */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */

@@ -62,6 +62,9 @@ struct Workspace {
     BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr; size_t desc_cap = 0;
     std::vector<BatchDesc> uploaded;
     std::vector<hipEvent_t> events;
+    // wide-query form shared across workgroups: partial count planes + one arrival counter per workgroup (grow-only)
+    uint4* d_split = nullptr; size_t split_bytes = 0;
+    uint32_t* d_split_cnt = nullptr; size_t split_cnt_n = 0;
     hipEvent_t done = nullptr;                // recorded behind the counter read-back
     bool busy = false;
 };
@@ -150,6 +153,8 @@ extern uint32_t g_single_launch;
 // pm_set_option("wide_query"): 0 = automatic (few long queries: several lane groups share a query), 1 = always
 // where instantiated (128+ k-mers per query), 2 = never
 extern uint32_t g_wide_query;
+// pm_set_option("wide_query_split"): 0 = automatic number of workgroups that share a long query's steps, 1 = never split, n = force n
+extern uint32_t g_wq_split;
 
 // pm_search.cpp: cobs' line order on records: (slot, query, count records first, score desc, doc asc)
 bool hit_less(const pm_hit_t& a, const pm_hit_t& b);

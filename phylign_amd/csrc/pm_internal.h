@@ -53,6 +53,10 @@ struct ScanArgs {
     uint64_t        run_cap;
     uint32_t        wide_query; // 1: several lane groups of a workgroup share one query (k_scan<..., WQ>)
     uint32_t        wq_groups;  // ... at most this many (power of two, 4 ... 256; capped by 256 / lanes per row)
+    uint32_t        nsplit;     // wide-query form: workgroups (gridDim.z) that share the steps of a tile's queries (1 = none)
+    uint32_t        pad2_;
+    uint4*          split_slabs;   // nsplit > 1: [workgroup (x, y)][z][plane][256 / groups per query] partial count planes
+    uint32_t*       split_cnt;     // ... and one arrival counter per workgroup (x, y), zeroed ahead of the launch
 };
 
 // launchers (pm_kernels.hip); all asynchronous on `st`, return hipError_t

@@ -340,7 +340,13 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
     constexpr int TS = PM_SCAN_TERMS;                 // k-mers per step: 8 (or 4): loads in flight per lane
     constexpr uint32_t SPB = 8 / TS;                  // steps per 8-slot hash block
     const uint32_t trips = WQ ? (wmax * SPB + ngrp - 1u) / ngrp : wmax * SPB;
-    for (uint32_t it = 0; it < trips; ++it) {
+    // wide-query form across workgroups: gridDim.z workgroups share the steps of a tile's queries (few, very long
+    // queries: a chromosome-sized contig is 125 000 steps); each takes a contiguous range, the last one to arrive adds up
+    const uint32_t nsplit = WQ ? a.nsplit : 1u;
+    const uint32_t seg = (trips + nsplit - 1u) / nsplit;
+    const uint32_t it_begin = WQ ? blockIdx.z * seg : 0u;
+    const uint32_t it_end = WQ ? (it_begin + seg < trips ? it_begin + seg : trips) : trips;
+    for (uint32_t it = it_begin; it < it_end; ++it) {
         const uint32_t sidx = WQ ? it * ngrp + sub : it;          // my step of the query
         const uint32_t b = sidx / SPB, t0i = sidx * TS;           // block, first k-mer of this step
         if (!WQ && a.bound) {
@@ -475,6 +481,66 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
             }
         }
     }
+    // ---- measurement option: how many row chunks were really gathered (threshold bound on/off).
+    // Bytes are counted the algorithmic way (row padding excluded), one sharded atomic per wavefront.
+    if (a.fetch_count) {
+        const uint64_t rb = ((uint64_t)bd.n_docs + 7u) >> 3;
+        const uint64_t vb = boff >= rb ? 0ull : (rb - boff < 16ull ? rb - boff : 16ull);
+        unsigned long long v = (unsigned long long)nfetch * vb;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t lo_ = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+            const uint32_t hi_ = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+            v += ((unsigned long long)hi_ << 32) | lo_;
+        }
+        if (lane == 0 && v != 0ull)
+            atomicAdd(a.fetch_count + ((blockIdx.x * 4u + (uint32_t)wave) & (a.fetch_shards - 1u)), v);
+    }
+
+    if constexpr (WQ) {
+        if (nsplit > 1u) {
+            // partial counts of this workgroup's step range -> global slabs; the workgroup that draws the last ticket of
+            // the tile adds the others' slabs to its own registers and runs the epilogue.  Hand-off by the counter form
+            // of an agent-scope release / acquire pair (cdna_hip_programming.md, section 5: split-K reduction): plain
+            // stores, every wave drains them, barrier, lane 0 releases + takes a ticket, the last arriver acquires.
+            __shared__ uint32_t last_flag;
+            const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
+            const uint32_t ow_n = 256u / ngrp;                                   // lanes that hold totals in a workgroup
+            const uint32_t ow = (gi / ngrp) * g + c;
+            // (a workgroup's region is sized for the most owner lanes any lane-group width has: 256 / 4)
+            u32x4* slab = reinterpret_cast<u32x4*>(a.split_slabs) + ((size_t)blk * nsplit) * (size_t)(P * 64);
+            if (sub == 0u) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) slab[((size_t)blockIdx.z * P + (size_t)p) * ow_n + ow] = pl[p];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t t = __hip_atomic_fetch_add(a.split_cnt + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t last = (t == nsplit - 1u) ? 1u : 0u;
+                if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                last_flag = last;
+            }
+            __syncthreads();
+            if (last_flag == 0u) return;
+            if (sub == 0u) {
+                for (uint32_t z = 0; z < nsplit; ++z) {
+                    if (z == blockIdx.z) continue;
+                    u32x4 carry = (u32x4)(0u);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const u32x4 o = slab[((size_t)z * P + (size_t)p) * ow_n + ow];
+                        const u32x4 u = pl[p] ^ o;
+                        const u32x4 sum = u ^ carry;
+                        carry = (u & carry) | (pl[p] & o);
+                        pl[p] = sum;
+                    }
+                }
+            }
+        }
+    }
     const bool owner = !WQ || sub == 0u;              // the group that holds the query's total counts
 
     // ---- a7: score >= thr, bit-sliced: carry-out of score + (2^P - thr).
@@ -518,22 +584,6 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
         for (int o = (int)(g >> 1); o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
         return v;
     };
-
-    // ---- measurement option: how many row chunks were really gathered (threshold bound on/off).
-    // Bytes are counted the algorithmic way (row padding excluded), one sharded atomic per wavefront.
-    if (a.fetch_count) {
-        const uint64_t rb = ((uint64_t)bd.n_docs + 7u) >> 3;
-        const uint64_t vb = boff >= rb ? 0ull : (rb - boff < 16ull ? rb - boff : 16ull);
-        unsigned long long v = (unsigned long long)nfetch * vb;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t lo_ = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
-            const uint32_t hi_ = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-            v += ((unsigned long long)hi_ << 32) | lo_;
-        }
-        if (lane == 0 && v != 0ull)
-            atomicAdd(a.fetch_count + ((blockIdx.x * 4u + (uint32_t)wave) & (a.fetch_shards - 1u)), v);
-    }
 
     // ---- a8 fused: keep the n best documents plus ties with the n-th
     // (scripts/postprocess_cobs.py:31-39): raise the cut to the n-th largest score
@@ -642,6 +692,7 @@ static hipError_t scan_dispatch_nh(const ScanArgs& a, uint32_t slabs, hipStream_
     dim3 grid(G > 0 ? a.n_batches * a.tiles : a.total_blocks, slabs, 1);
     if constexpr (P >= 10) {
         if (a.wide_query) {
+            grid.z = a.nsplit > 1u ? a.nsplit : 1u;
             if (a.nh == 1) hipLaunchKernelGGL((k_scan<G, P, true, true>), grid, dim3(256), 0, st, a);
             else           hipLaunchKernelGGL((k_scan<G, P, false, true>), grid, dim3(256), 0, st, a);
             return hipGetLastError();

@@ -21,6 +21,7 @@ uint32_t g_threshold_bound = 1;
 uint32_t g_count_fetched = 0;
 uint32_t g_single_launch = 0;
 uint32_t g_wide_query = 0;
+uint32_t g_wq_split = 0;
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
@@ -59,6 +60,8 @@ extern "C" void pm_shutdown(void) {
         if (w->h_cnt) (void)hipHostFree(w->h_cnt);
         if (w->d_desc) (void)hipFree(w->d_desc);
         if (w->h_desc) (void)hipHostFree(w->h_desc);
+        if (w->d_split) (void)hipFree(w->d_split);
+        if (w->d_split_cnt) (void)hipFree(w->d_split_cnt);
         for (auto e : w->events) (void)hipEventDestroy(e);
         if (w->done) (void)hipEventDestroy(w->done);
         delete w;
@@ -92,6 +95,11 @@ extern "C" int pm_set_option(const char* name, int64_t value) {
     if (strcmp(name, "wide_query") == 0) {
         if (value < 0 || value > 2) return fail(PM_EINVAL, "wide_query takes 0 (auto), 1 (always) or 2 (never)");
         g_wide_query = (uint32_t)value;
+        return PM_OK;
+    }
+    if (strcmp(name, "wide_query_split") == 0) {
+        if (value < 0 || value > 256) return fail(PM_EINVAL, "wide_query_split takes 0 (auto), 1 (off) or a count up to 256");
+        g_wq_split = (uint32_t)value;
         return PM_OK;
     }
     return fail(PM_EINVAL, "unknown option '%s'", name);

@@ -334,6 +334,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             a.tiles = 0; a.total_blocks = 0;
             a.wq_groups = use_wq[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
             a.wide_query = a.wq_groups ? 1u : 0u;
+            a.nsplit = 1; a.pad2_ = 0; a.split_slabs = nullptr; a.split_cnt = nullptr;
             if (g.g > 0) {
                 const uint32_t qpb = scan_queries_per_block(g.g, a.wq_groups);
                 a.tiles = (e - b + qpb - 1) / qpb;
@@ -350,6 +351,41 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             a.runs = hb.p + hb.cap; a.run_cap = run_cap_of(hb.cap);
             if ((uint64_t)a.tiles * a.n_batches > 0x7FFFFFFFull)
                 return fail(PM_ERANGE, "launch grid too large (%u tiles x %u batches)", a.tiles, a.n_batches);
+            if (a.wide_query && g_wq_split != 1) {
+                // few, very long queries: even with a whole workgroup per query the launch is a few hundred
+                // workgroups.  nsplit workgroups then share the steps of each tile (gridDim.z); partial count planes
+                // meet in global slabs (k_scan, "wide-query form across workgroups").
+                const uint64_t blocks = (uint64_t)(g.g > 0 ? a.n_batches * a.tiles : a.total_blocks) * g.slabs;
+                uint32_t max_nt = 0;
+                for (uint32_t i = b; i < e; ++i) max_nt = std::max(max_nt, q->n_terms[q->qmap[i]]);
+                int min_g = 64;
+                for (size_t u : g.members) min_g = std::min(min_g, units[u].ix->g);
+                const uint32_t ngrp_max = std::min<uint32_t>(a.wq_groups, 256u / (uint32_t)min_g);
+                const uint32_t trips = ((max_nt + 7u) / 8u + ngrp_max - 1u) / std::max<uint32_t>(ngrp_max, 1u);
+                uint32_t ns = g_wq_split ? g_wq_split : (uint32_t)std::min<uint64_t>(64, (2048 + blocks - 1) / std::max<uint64_t>(blocks, 1));
+                if (!g_wq_split) ns = std::min<uint32_t>(ns, std::max<uint32_t>(1u, trips / 64u));     // >= 64 steps per workgroup
+                ns = std::min<uint32_t>(ns, std::max<uint32_t>(trips, 1u));
+                if (ns > 1 && blocks * ns <= 0x7FFFFFFFull && ns <= 65535u) {
+                    const uint32_t ngrp_min = 4;                  // slabs are sized for the smallest groups-per-query count (256 / 4 lanes)
+                    const size_t need = (size_t)blocks * ns * (size_t)kPlaneClass[c] * (256u / ngrp_min) * sizeof(uint4);
+                    if (ws->split_bytes < need) {
+                        HIPCHK(hipStreamSynchronize(st));         // an earlier launch of this search may still use the old slabs
+                        if (ws->d_split) (void)hipFree(ws->d_split);
+                        ws->d_split = nullptr; ws->split_bytes = 0;
+                        HIPCHK(hipMalloc((void**)&ws->d_split, need));
+                        ws->split_bytes = need;
+                    }
+                    if (ws->split_cnt_n < blocks) {
+                        HIPCHK(hipStreamSynchronize(st));
+                        if (ws->d_split_cnt) (void)hipFree(ws->d_split_cnt);
+                        ws->d_split_cnt = nullptr; ws->split_cnt_n = 0;
+                        HIPCHK(hipMalloc((void**)&ws->d_split_cnt, (size_t)blocks * sizeof(uint32_t)));
+                        ws->split_cnt_n = (size_t)blocks;
+                    }
+                    HIPCHK(hipMemsetAsync(ws->d_split_cnt, 0, (size_t)blocks * sizeof(uint32_t), st));
+                    a.nsplit = ns; a.split_slabs = ws->d_split; a.split_cnt = ws->d_split_cnt;
+                }
+            }
             hipEvent_t es, ee;
             { int rc = ws_event(ws, r->nev++, &es); if (rc) return rc; }
             { int rc = ws_event(ws, r->nev++, &ee); if (rc) return rc; }

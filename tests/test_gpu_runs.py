@@ -306,7 +306,19 @@ def test_wide_query_form_is_bit_identical(pm, oracle, n_docs):
                 assert np.array_equal(got[(1, thr, n)], got[(2, thr, n)]), (thr, n)
                 assert np.array_equal(got[(0, thr, n)], got[(2, thr, n)]), (thr, n)
             assert pm.format_hits(ix, q, got[(1, thr, 0)], slot=0) == oracle.query_file(index, fasta, thr)
+        # the same form with the steps of every query shared by 2, 5 and 16 workgroups (partial planes meet in global
+        # slabs, the last workgroup to arrive adds them up): same records again, run twice over the same slabs
+        pm.set_option("wide_query", 1)
+        for split in (2, 5, 16, 5):
+            pm.set_option("wide_query_split", split)
+            for thr in (0.7, 0.0):
+                for n in (0, 3):
+                    res = pm.search([ix, other], q, thr, nb_best_hits=n)
+                    assert np.array_equal(res.hits(), got[(2, thr, n)]), (split, thr, n)
     finally:
         pm.set_option("wide_query", 0)
+        pm.set_option("wide_query_split", 0)
     with pytest.raises(pm.PMError):
         pm.set_option("wide_query", 3)
+    with pytest.raises(pm.PMError):
+        pm.set_option("wide_query_split", 1000)

@@ -242,6 +242,8 @@ def main():
         pm.set_option("single_launch", 1)
     if os.environ.get("PM_WIDE_QUERY"):
         pm.set_option("wide_query", int(os.environ["PM_WIDE_QUERY"]))
+    if os.environ.get("PM_WQ_SPLIT"):
+        pm.set_option("wide_query_split", int(os.environ["PM_WQ_SPLIT"]))
     dev = pm.device_info()
     log(f"[bench] {dev['name']} free {dev['hbm_free'] / 1e9:.1f} GB of {dev['hbm_total'] / 1e9:.1f} GB")
 

@@ -322,3 +322,37 @@ def test_wide_query_form_is_bit_identical(pm, oracle, n_docs):
         pm.set_option("wide_query", 3)
     with pytest.raises(pm.PMError):
         pm.set_option("wide_query_split", 1000)
+
+
+def test_long_queries_shared_across_workgroups_at_scale(pm):
+    """the cross-workgroup hand-off of the wide-query form under real load: six 300-kbp queries against a wide and a
+    narrow 661k-shaped batch (1.5 GB of signatures, planted hits around the threshold); the records with the steps of a
+    query shared by 7 and 24 workgroups, and with the automatic choice, equal the unsplit form's -- three rounds over the
+    same slabs, every record compared"""
+    from phylign_amd import workload as W
+    fasta, _ = W.make_queries(6, 300_030, seed=77)
+    q = pm.Queries(fasta)
+    hashes = q.hash_terms(1, 1).reshape(6, 300_000)
+    ixs = [pm.Index.synth(5, 4000, 2_500_000), pm.Index.synth(6, 300, 9_000_000)]
+    rng = np.random.default_rng(4)
+    for ix in ixs:
+        info = ix.info
+        rows, docs = [], []
+        for qi in range(6):
+            for d, frac in zip(rng.choice(info.n_docs, size=5, replace=False), (1.0, 0.75, 0.7001, 0.6999, 0.5)):
+                m = int(np.ceil(frac * 300_000))
+                rows.append(hashes[qi, :m] % np.uint64(info.signature_size))
+                docs.append(np.full(m, d, dtype=np.uint32))
+        ix.plant(np.concatenate(rows), np.concatenate(docs))
+    try:
+        pm.set_option("wide_query_split", 1)
+        base = pm.search(ixs, q, 0.7, nb_best_hits=100)
+        ref = base.hits()
+        assert len(ref) >= 2 * 6 * 3 and all(",WQ>" in L["kernel"] for L in base.launches())
+        for rnd in range(3):
+            for split in (7, 0, 24):
+                pm.set_option("wide_query_split", split)
+                got = pm.search(ixs, q, 0.7, nb_best_hits=100).hits()
+                assert np.array_equal(got, ref), (rnd, split)
+    finally:
+        pm.set_option("wide_query_split", 0)

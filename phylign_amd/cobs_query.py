@@ -66,11 +66,18 @@ def run_query(args, out=None):
     size_hint = args.index_sizes[0] if args.index_sizes else 0
     if args.server:
         from .server import request
-        with open(args.query_file, "rb") as f:
-            fasta = f.read()
-        head, body = request(pick_server(args.server, args.index[0]), {"op": "query", "index": os.path.abspath(args.index[0]), "index_size": size_hint,
-                                           "fasta_len": len(fasta), "threshold": args.threshold,
-                                           "nb_best_hits": args.nb_best_hits}, fasta)
+        # the server runs on this host (unix socket): it is told where the query file is instead of being sent its
+        # bytes; a pipe or anything else that cannot be re-opened is sent
+        req = {"op": "query", "index": os.path.abspath(args.index[0]), "index_size": size_hint,
+               "threshold": args.threshold, "nb_best_hits": args.nb_best_hits}
+        fasta = b""
+        if os.path.isfile(args.query_file):
+            req["fasta_path"] = os.path.abspath(args.query_file)
+        else:
+            with open(args.query_file, "rb") as f:
+                fasta = f.read()
+            req["fasta_len"] = len(fasta)
+        head, body = request(pick_server(args.server, args.index[0]), req, fasta)
         if not head.get("ok"):
             raise RuntimeError(head.get("error", "server error"))
         out.write(body)

@@ -170,7 +170,7 @@ class ResidentSource:
 
 
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
-              want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None):
+              want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
     `batches`).  Returns (report dict, pm.Merge or None).  keep_texts: optional dict that receives
     {batch: post-filtered text} (tests)."""
@@ -288,8 +288,8 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
                         info = ix.info
                         if ix.device != pm.bound_device():
                             raise SystemExit(f"batch {batches[pos]}: matrix is on GPU {ix.device}, this rank drives GPU {pm.bound_device()}")
-                        if info.term_size != 31:
-                            raise SystemExit(f"batch {batches[pos]}: term_size {info.term_size} != 31")
+                        if info.term_size != kmer_size:
+                            raise SystemExit(f"batch {batches[pos]}: term_size {info.term_size} != {kmer_size} (--kmer-size)")
                     tq = time.perf_counter()
                     cur = (group, pm.search_async([ix for _, ix, _ in group], queries, threshold, nb_best_hits=max(nb, 0)), tq)
                     left -= len(group)
@@ -336,6 +336,7 @@ def main(argv=None):
     ap.add_argument("--filter-out", default=None)
     ap.add_argument("--loaders", type=int, default=4, help="concurrent xz decoders per rank")
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
+    ap.add_argument("--kmer-size", type=int, default=31, help="k of the indexes (31 for the 661k collection); every batch's header is checked against it")
     ap.add_argument("--max-group", type=int, default=0, help="most batches fused into one search (0 = every resident batch)")
     ap.add_argument("--raw-queries", action="store_true",
                     help="--queries is an unprocessed FASTA/FASTQ (multi-line, lower case, IUPAC codes): apply rule "
@@ -385,11 +386,11 @@ def main(argv=None):
     qfile = qfile[:-3] if qfile.endswith(".fa") else qfile
     with open(args.queries, "rb") as f:
         fasta = f.read()
-    queries = pm.Queries(fasta, term_size=31, normalise=args.raw_queries)   # 661k indexes are 31-mer indexes; checked per batch
+    queries = pm.Queries(fasta, term_size=args.kmer_size, normalise=args.raw_queries)   # checked against every batch's header
     budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else None
     report, merge = run_stage(pm, batches, mine, source, queries, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                               want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
-                              max_group=args.max_group)
+                              max_group=args.max_group, kmer_size=args.kmer_size)
 
     # ---- 04_filter: one gather of what every rank's merge kept, rank 0 adds the parts and emits
     t_f = time.perf_counter()

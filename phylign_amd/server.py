@@ -164,19 +164,24 @@ class Dispatcher(threading.Thread):
         self.searches = self.fused_jobs = self.max_fused = 0
         self.qcache = OrderedDict()            # fasta digest -> Queries (a few recent query sets stay parsed)
 
-    def submit(self, ix, fasta, threshold, nb):
-        job = {"ix": ix, "fasta": fasta, "threshold": float(threshold), "nb": nb, "done": threading.Event()}
+    def submit(self, ix, fasta, threshold, nb, fkey=None):
+        """fasta: the query bytes, or a callable that returns them (read only when the set is not parsed yet);
+        fkey identifies them: (path, mtime, size) of the file a local client named, else their SHA-1 (computed by
+        the handler thread, not by the dispatcher)"""
+        if fkey is None:
+            fkey = hashlib.sha1(fasta).digest()
+        job = {"ix": ix, "fasta": fasta, "fkey": fkey, "threshold": float(threshold), "nb": nb, "done": threading.Event()}
         self.jobs.put(job)
         job["done"].wait()
         if "error" in job:
             raise job["error"]
         return job["queries"], job["hits"], job["slot"]
 
-    def _queries(self, fasta, term_size):
-        key = (hashlib.sha1(fasta).digest(), term_size)
+    def _queries(self, fasta, fkey, term_size):
+        key = (fkey, term_size)
         q = self.qcache.get(key)
         if q is None:
-            q = self.pm.Queries(fasta, term_size=term_size)
+            q = self.pm.Queries(fasta() if callable(fasta) else fasta, term_size=term_size)
             self.qcache[key] = q
             while len(self.qcache) > 4:
                 self.qcache.popitem(last=False)      # freed when the last job that holds it lets go (refcount)
@@ -203,11 +208,11 @@ class Dispatcher(threading.Thread):
                 batch.append(j)
             groups = OrderedDict()
             for j in batch:
-                k = (hashlib.sha1(j["fasta"]).digest(), j["threshold"], j["nb"], j["ix"].info.term_size)
+                k = (j["fkey"], j["threshold"], j["nb"], j["ix"].info.term_size)
                 groups.setdefault(k, []).append(j)
             for (_, thr, nb, k), jobs in groups.items():
                 try:
-                    q = self._queries(jobs[0]["fasta"], k)
+                    q = self._queries(jobs[0]["fasta"], jobs[0]["fkey"], k)
                     # the same batch asked for twice in one group is searched once
                     uniq, slot_of = [], {}
                     for j in jobs:
@@ -287,12 +292,20 @@ def serve(sock_path, device=0, max_gb=0.0, coalesce_ms=0.0, preload=(), ready_fd
                 op = req.get("op")
                 if op == "query":
                     t0 = time.time()
-                    fasta = _recv_exact(conn, int(req["fasta_len"])) if "fasta_len" in req else open(req["fasta_path"], "rb").read()
+                    if "fasta_len" in req:
+                        fasta, fkey = _recv_exact(conn, int(req["fasta_len"])), None
+                    else:
+                        # a local client names the file: 305 per-batch jobs of one query set cost one read and one parse,
+                        # not 305 transfers of (for a million reads) 160 MB each
+                        fp = req["fasta_path"]
+                        fst = os.stat(fp)
+                        fkey = (os.path.realpath(fp), fst.st_mtime_ns, fst.st_size)
+                        fasta = lambda fp=fp: open(fp, "rb").read()
                     ix, key, cached = cache.acquire(req["index"], int(req.get("index_size", 0)))
                     try:
                         t1 = time.time()
                         nb = req.get("nb_best_hits")
-                        q, hits, slot = disp.submit(ix, fasta, float(req.get("threshold", 0.8)), nb)
+                        q, hits, slot = disp.submit(ix, fasta, float(req.get("threshold", 0.8)), nb, fkey)
                         t2 = time.time()
                         text = pm.format_hits(ix, q, hits, slot=slot, nb_best_hits=-1 if nb is None else max(int(nb), 0))
                     finally:

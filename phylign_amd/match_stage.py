@@ -56,16 +56,6 @@ def read_sizes(path):
     return out
 
 
-def lpt(weights, n):
-    order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
-    load, parts = [0] * n, [[] for _ in range(n)]
-    for i in order:
-        r = min(range(n), key=lambda k: (load[k], k))
-        parts[r].append(i)
-        load[r] += weights[i]
-    return [sorted(p) for p in parts]
-
-
 class Admission:
     """HBM budget for decoded-but-not-yet-searched indexes.  Loaders are admitted strictly in
     submission order (a ticket counter) and a reservation is only returned after its batch was

@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <sys/stat.h>
 #include <thread>
 #include <tuple>
 #include <unistd.h>
@@ -140,6 +141,8 @@ struct pm_queries {
     uint64_t epoch = 0;
 };
 
+// pm_index.cpp: pooled staging buffers of the parallel file loader (released by pm_shutdown)
+void release_stage_pool();
 // pm_queries.cpp: HBM copies of a query set on first use; device hashes per (canonicalize, num_hashes)
 int upload_queries(pm_queries* q);
 int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out);

@@ -210,6 +210,114 @@ static int stream_matrix(Reader& rd, pm_index* ix, uint64_t rb, uint64_t S) {
     return PM_OK;
 }
 
+// The same for a REGULAR FILE (a decompressed index on disk or in the page cache: rule decompress_cobs,
+// Snakefile:364-387, index_load_mode mem-disk): a single read() loop tops out at the speed of one memcpy out of the
+// page cache (~20 GB/s), a third of PCIe Gen5.  Here `nthreads` workers pread() alternate chunks into their own pinned
+// double buffers and queue H2D + re-stride on their own streams, so several copies are in flight.
+// staging of one reader thread: two pinned chunks, two device chunks, their events and a stream.  Pinning memory is slow
+// (tens of ms per buffer), a whole-stage run loads dozens of indexes: the sets are pooled for the life of the library.
+struct StageSet { uint8_t* hbuf[2]; uint8_t* dbuf[2]; hipEvent_t ev[2]; hipStream_t st; };
+static std::mutex g_stage_mu;
+static std::vector<StageSet> g_stage_pool;
+static constexpr size_t kStageBytes = 32ull << 20;
+static hipError_t take_stage(StageSet* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        if (!g_stage_pool.empty()) { *out = g_stage_pool.back(); g_stage_pool.pop_back(); return hipSuccess; }
+    }
+    StageSet s{};
+    hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void**)&s.hbuf[i], kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.dbuf[i], kStageBytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        for (int i = 0; i < 2; ++i) {
+            if (s.hbuf[i]) (void)hipHostFree(s.hbuf[i]);
+            if (s.dbuf[i]) (void)hipFree(s.dbuf[i]);
+            if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
+        }
+        if (s.st) (void)hipStreamDestroy(s.st);
+        return e;
+    }
+    *out = s;
+    return hipSuccess;
+}
+static void give_stage(const StageSet& s) {
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        if (g_ctx.ready && g_stage_pool.size() < 16) { g_stage_pool.push_back(s); return; }
+    }
+    for (int i = 0; i < 2; ++i) { (void)hipHostFree(s.hbuf[i]); (void)hipFree(s.dbuf[i]); (void)hipEventDestroy(s.ev[i]); }
+    (void)hipStreamDestroy(s.st);
+}
+void release_stage_pool() {                    // pm_shutdown
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    for (auto& s : g_stage_pool) {
+        for (int i = 0; i < 2; ++i) { (void)hipHostFree(s.hbuf[i]); (void)hipFree(s.dbuf[i]); (void)hipEventDestroy(s.ev[i]); }
+        (void)hipStreamDestroy(s.st);
+    }
+    g_stage_pool.clear();
+}
+
+static int stream_matrix_file(int fd, uint64_t file_off, pm_index* ix, uint64_t rb, uint64_t S) {
+    const uint64_t stride = ix->info.stride;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (32ull << 20) / rb);
+    const uint64_t n_chunks = (S + chunk_rows - 1) / chunk_rows;
+    int want = 6;                                               // PM_LOAD_THREADS: readers per index file
+    if (const char* env = getenv("PM_LOAD_THREADS")) want = std::max(1, std::min(32, atoi(env)));
+    const int nthreads = (int)std::min<uint64_t>((uint64_t)want, n_chunks);
+    std::vector<int> rcs((size_t)nthreads, PM_OK);
+    std::vector<std::string> errs((size_t)nthreads);
+    const int device = g_ctx.device;
+    auto worker = [&](int t) {
+        char msg[256];
+        hipError_t e = hipSetDevice(device);
+        StageSet sg{};
+        bool have = false;
+        if (e == hipSuccess) { e = take_stage(&sg); have = e == hipSuccess; }
+        bool used[2] = {false, false}; int cur = 0;
+        for (uint64_t c = (uint64_t)t; c < n_chunks && e == hipSuccess && rcs[(size_t)t] == PM_OK; c += (uint64_t)nthreads) {
+            const uint64_t row = c * chunk_rows, nrows = std::min<uint64_t>(chunk_rows, S - row);
+            const size_t nbytes = (size_t)(nrows * rb);
+            if (used[cur]) { e = hipEventSynchronize(sg.ev[cur]); if (e != hipSuccess) break; }
+            size_t got = 0;
+            while (got < nbytes) {
+                ssize_t r = pread(fd, sg.hbuf[cur] + got, nbytes - got, (off_t)(file_off + row * rb + got));
+                if (r < 0) { if (errno == EINTR) continue; break; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            if (got != nbytes) {
+                snprintf(msg, sizeof msg, "index file ended after %llu of %llu matrix bytes",
+                         (unsigned long long)(row * rb + got), (unsigned long long)(S * rb));
+                errs[(size_t)t] = msg; rcs[(size_t)t] = PM_EIO;
+                break;
+            }
+            e = hipMemcpyAsync(sg.dbuf[cur], sg.hbuf[cur], nbytes, hipMemcpyHostToDevice, sg.st);
+            if (e == hipSuccess) e = launch_restride(sg.dbuf[cur], rb, ix->d_matrix + row * stride, stride, nrows, sg.st);
+            if (e == hipSuccess) e = hipEventRecord(sg.ev[cur], sg.st);
+            used[cur] = true; cur ^= 1;
+        }
+        if (have) {
+            hipError_t e2 = hipStreamSynchronize(sg.st);          // nothing of this load may still use the set
+            if (e == hipSuccess) e = e2;
+            give_stage(sg);
+        }
+        if (e != hipSuccess && rcs[(size_t)t] == PM_OK) {
+            snprintf(msg, sizeof msg, "index upload: %s", hipGetErrorString(e)); errs[(size_t)t] = msg; rcs[(size_t)t] = PM_EHIP;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nthreads; ++t)
+        if (rcs[(size_t)t] != PM_OK) return fail(rcs[(size_t)t], "%s", errs[(size_t)t].c_str());
+    return PM_OK;
+}
+
 // Compact index header ("COBS:" "COMPACT_INDEX", upstream
 // cobs/file/compact_index_header.cpp; Phylign itself only uses classic indexes,
 // Snakefile:48 -- SURVEY.md 8f rank 3): u32 version, u32 term_size, u8
@@ -290,9 +398,16 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
         if (size_hint && size_hint != h.data_off + S * rb)
             fprintf(stderr, "phylign_match: warning: --index-sizes %llu != header-implied %llu bytes\n",
                     (unsigned long long)size_hint, (unsigned long long)(h.data_off + S * rb));
-        rd.pending.assign(head.begin() + (long)h.data_off, head.end());
-        rd.pend_pos = 0;
-        rc = stream_matrix(rd, ix, rb, S);
+        struct stat fst;
+        const off_t pos = (rd.fd >= 0 && !rd.mem) ? lseek(rd.fd, 0, SEEK_CUR) : (off_t)-1;
+        if (pos >= (off_t)head.size() && fstat(rd.fd, &fst) == 0 && S_ISREG(fst.st_mode) && S * rb >= (256ull << 20)) {
+            // seekable: several readers in parallel (the index began at pos - head.size() of the file)
+            rc = stream_matrix_file(rd.fd, (uint64_t)(pos - (off_t)head.size()) + h.data_off, ix, rb, S);
+        } else {
+            rd.pending.assign(head.begin() + (long)h.data_off, head.end());
+            rd.pend_pos = 0;
+            rc = stream_matrix(rd, ix, rb, S);
+        }
         if (rc) { pm_index_free(ix); return rc; }
         *out = ix;
         return PM_OK;

@@ -66,6 +66,7 @@ extern "C" void pm_shutdown(void) {
         if (w->done) (void)hipEventDestroy(w->done);
         delete w;
     }
+    release_stage_pool();
     for (auto& b : g_ctx.free_hits) (void)hipFree(b.p);
     if (g_ctx.d_fetch) (void)hipFree(g_ctx.d_fetch);
     for (auto& b : g_ctx.free_pinned) (void)hipHostFree(b.p);

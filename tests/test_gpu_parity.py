@@ -95,6 +95,44 @@ def test_mixed_lengths_and_plane_classes(pm, oracle):
     assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"3", "7", "10", "16", "20", "24"}
 
 
+def test_large_index_file_goes_through_the_parallel_reader(pm, oracle, tmp_path):
+    """a decompressed index on disk (rule decompress_cobs / index_load_mode mem-disk): files of 256 MiB and more are
+    read by several pread() workers with pooled pinned staging; every row lands where the serial pipe path puts it,
+    a truncated file is PM_EIO, and the same fd positioned past a prefix still loads"""
+    rng = np.random.default_rng(21)
+    n_docs, S = 2371, 1_000_003                       # 297-byte rows -> 384-byte stride, 297 MB of matrix, 10 chunks
+    names = [f"{i:05x}_DOC{i}" for i in range(n_docs)]
+    idx = oracle.make_index(31, 1, S, 1, names)
+    h = oracle.header_parse(idx)
+    rb = (n_docs + 7) // 8
+    body = rng.integers(0, 256, size=S * rb, dtype=np.uint8)
+    body.reshape(S, rb)[:, -1] &= np.uint8((1 << (n_docs - (rb - 1) * 8)) - 1)
+    idx[h.data_off:] = body
+    path = tmp_path / "big__01.cobs_classic"
+    idx.tofile(path)
+    ix = pm.Index.load_file(str(path))
+    piped = pm.Index.load_mem(idx)                    # the serial reader
+    for r in (0, 1, 87_381, 87_382, 500_000, S - 2, S - 1):          # chunk borders of 32 MiB / 297 B among them
+        want = body[r * rb:(r + 1) * rb]
+        assert np.array_equal(ix.read_row(r), want) and np.array_equal(piped.read_row(r), want), r
+    assert np.array_equal(ix.read_rows(262_140, 3000), piped.read_rows(262_140, 3000))
+    ix.free(); piped.free()
+    with open(path, "rb") as f:                       # an fd that does not start at the index
+        pre = tmp_path / "prefixed.bin"
+        pre.write_bytes(b"x" * 4096 + f.read())
+    fd = os.open(pre, os.O_RDONLY)
+    os.lseek(fd, 4096, os.SEEK_SET)
+    ix2 = pm.Index.load_fd(fd)
+    os.close(fd)
+    assert np.array_equal(ix2.read_row(S - 1), body[(S - 1) * rb:])
+    ix2.free()
+    with open(path, "r+b") as f:
+        f.truncate(h.data_off + (S - 5) * rb)
+    with pytest.raises(pm.PMError) as e:
+        pm.Index.load_file(str(path))
+    assert e.value.code == -4
+
+
 def test_header_with_an_impossible_row_count_is_rejected_before_allocation(pm, oracle):
     """a header whose signature_size makes rows x stride wrap around 2^64 (or just exceed HBM) is PM_EFORMAT:
     nothing is allocated, nothing is uploaded next to other resident indexes"""

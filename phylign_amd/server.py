@@ -270,6 +270,7 @@ def serve(sock_path, device=0, max_gb=0.0, coalesce_ms=0.0, preload=(), ready_fd
     print(f"[phylign_amd.server] {pm.device_info()['name']} listening on {sock_path}", file=sys.stderr, flush=True)
     stop = threading.Event()
     preloading = {"left": 0, "errors": []}
+    pre_mu = threading.Lock()
 
     def preload_paths(paths):
         def one(p):
@@ -277,10 +278,13 @@ def serve(sock_path, device=0, max_gb=0.0, coalesce_ms=0.0, preload=(), ready_fd
                 _, key, _ = cache.acquire(p)
                 cache.release(key)
             except Exception as e:
-                preloading["errors"].append(f"{p}: {e}")
+                with pre_mu:
+                    preloading["errors"].append(f"{p}: {e}")
             finally:
-                preloading["left"] -= 1
-        preloading["left"] += len(paths)
+                with pre_mu:
+                    preloading["left"] -= 1
+        with pre_mu:
+            preloading["left"] += len(paths)
         workers = [threading.Thread(target=lambda chunk=paths[i::4]: [one(p) for p in chunk], daemon=True) for i in range(4)]
         for w in workers:
             w.start()

@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--cpu-sample-gb", type=float, default=0.0,
                     help="host-RAM size of the CPU baseline's index sample (0 = min(48 GB, 35 %% of the RAM available to the job))")
     ap.add_argument("--dump-hits", default=None, help="rank 0 saves the ordered hit records of the headline mode (.npy)")
+    ap.add_argument("--dump-full-hits", default=None, help="rank 0 saves the records of the full_collection leg (N >= 8 ranks) (.npy)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: hold only the shard rank --emulate-rank would get in an N-way split "
                          "(estimates the per-rank step time of a strong-scaling run; not a reported number)")
@@ -568,6 +569,66 @@ def main():
                                                                    clustered["fetch_all_rows"]["value"])
     pm.set_option("threshold_bound", 1)
 
+    # ---- BASELINE configs[3] on real GPUs: with 8 ranks (or BENCH_FULL_MIN_WORLD) ALL 305 batches of batches_full.txt are
+    # sharded over the ranks -- 1.06 TB of signatures, ~135 GB per GPU -- and the same query set is searched against the whole
+    # 661k collection with the per-step gather of hit records: whole-job k-mers/s against the full index.  The config-3 shard
+    # of every rank is freed first.  (One GPU holds the same shard in the `full_shard` object of the N = 1 line.)
+    full_collection = None
+    min_world_full = int(os.environ.get("BENCH_FULL_MIN_WORLD", "8"))
+    if world > 1 and world >= min_world_full and not args.no_full_shard and not args.only_headline and not args.emulate_world \
+            and args.workload == "config3":
+        for ix in indexes:
+            ix.free()
+        indexes = []
+        t0 = time.time()
+        fshapes = W.select("full")
+        if args.rows_divisor > 1:
+            fshapes = W.scale_shapes(fshapes, args.rows_divisor)
+        fparts = W.assign_batches(fshapes, world, capacity_bytes=int(dev["hbm_total"] * 0.85))
+        fbases, acc_b = [], 0
+        for r in range(world):
+            fbases.append(acc_b)
+            acc_b += len(fparts[r])
+        fplan, fsure = W.plant_plan(q.hash_terms(1, 1), nq, terms_per_q, fshapes)
+        for pos in fparts[rank]:
+            sh = fshapes[pos]
+            ix = pm.Index.synth(sh.batch_id, sh.n_docs, sh.signature_size, 1, 31, 661, layout=args.layout)
+            if pos in fplan:
+                ix.plant(*fplan[pos])
+            indexes.append(ix)
+        finfos = [ix.info for ix in indexes]
+        log(f"[bench] full_collection: rank0 holds {len(indexes)} of {len(fshapes)} batches, "
+            f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
+        saved = dict(cur)
+        cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fshapes), "slot_base": fbases[rank],
+                    "tag": f"full/{world}", "narrow_lines_per_kmer": narrow_lines(finfos)})
+        fc_steps = max(3, min(args.steps, 10))
+        full_collection = {"workload": f"all {len(fshapes)} batches of batches_full.txt ({sum(sh.index_bytes for sh in fshapes) / 1e12:.2f} TB of "
+                                       f"signatures, {cur['rowsum']} row bytes per k-mer) sharded over {world} ranks, {nq} x {args.qlen} bp queries, "
+                                       "one gather of hit records per step",
+                           "planted_pairs_at_or_above_threshold": fsure, "rank_batches": [len(p_) for p_ in fparts]}
+        fc_runs = {}
+        for m in modes:
+            r = timed_run(m == "threshold_bound", 2, fc_steps)
+            fc_runs[m] = r
+            full_collection[m] = summary(r, fc_steps, m, None)
+            full_collection[m]["rank_ms_per_step"] = [e / fc_steps * 1e3 for e in r["rank_elapsed"]]
+        if rank == 0:
+            same = bool(np.array_equal(fc_runs[modes[0]]["hits"], fc_runs[modes[1]]["hits"]))
+            n_real = int(np.count_nonzero(fc_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
+            full_collection["hits_identical"] = same
+            ok = ok and same and n_real >= fsure
+            if args.dump_full_hits:
+                pos_of = np.zeros(len(fshapes), dtype=np.uint32)
+                for r_ in range(world):
+                    for i, pos in enumerate(fparts[r_]):
+                        pos_of[fbases[r_] + i] = pos
+                h = fc_runs[modes[0]]["hits"].copy()
+                h["slot"] = pos_of[h["slot"]]
+                np.save(args.dump_full_hits, pm.sort_hits(np.ascontiguousarray(h)))
+        cur.clear(); cur.update(saved)
+        pm.set_option("threshold_bound", 1)
+
     # ---- BASELINE configs[1] read literally: "10k synthetic 31-mer queries" = ONE k-mer per query (hit <=> bit
     # set: with Bernoulli(1/4) signatures a quarter of all documents match every query, so this leg is bound by
     # writing hit records, not by the scan).  (a) config 2: one batch, latency of one query set; (b) the resident
@@ -715,6 +776,7 @@ def main():
         "clustered": clustered,
         "l31": l31,
         "full_shard": full_shard,
+        "full_collection": full_collection,
     }
     if args.emulate_world:
         out["emulated_shard"] = f"rank {part_id} of {nparts}"

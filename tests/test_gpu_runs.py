@@ -240,6 +240,23 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     assert part["ranks"] == 2 and len(part["rank_ms_per_step"]) == 2 and part["rank_devices"] == [0, 0]
     assert sum(part["rank_batches"]) == 64 and min(part["rank_batches"]) >= 1
     assert abs(max(part["rank_ms_per_step"]) - line2["ms_per_step"]) < 1e-6          # the job's step is the slowest rank's
+    # BASELINE configs[3]: with 8 ranks (here: 2, forced) all 305 batches are sharded over the ranks and searched with
+    # the per-step gather -- the records equal those of one rank that holds the whole (scaled) collection
+    fullc = tmp_path / "fullc.npy"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2"] + common + ["--dump-full-hits", str(fullc)], capture_output=True,
+                       env=dict(env2, BENCH_FULL_MIN_WORLD="2"))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line_fc = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    fc = line_fc["full_collection"]
+    assert fc["hits_identical"] and sum(fc["rank_batches"]) == 305 and len(fc["fetch_all_rows"]["rank_ms_per_step"]) == 2
+    assert fc["fetch_all_rows"]["hits"] >= fc["planted_pairs_at_or_above_threshold"] > 0
+    whole = tmp_path / "whole.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "full", "--no-l31", "--no-clustered"] + common +
+                       ["--dump-hits", str(whole)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert np.array_equal(np.load(fullc), np.load(whole))
     # one rank under the launcher the driver uses = the plain invocation (same records, a bench line of the same shape)
     solo = tmp_path / "solo.npy"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",

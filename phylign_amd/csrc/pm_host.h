@@ -25,6 +25,7 @@
 #include <sys/stat.h>
 #include <thread>
 #include <tuple>
+#include <unordered_map>
 #include <unistd.h>
 #include <vector>
 

@@ -207,7 +207,7 @@ struct pm_merge {
     const pm_queries* q = nullptr;
     uint32_t keep = 0;
     std::vector<MergeBatch> batches;
-    std::map<std::string, uint32_t> by_name;        // query name (first word) -> record index
+    std::unordered_map<std::string, uint32_t> by_name;        // query name (first word) -> record index
     std::vector<std::string> qnames;
     std::vector<std::vector<MergeItem>> items;
     std::vector<uint32_t> floor_;
@@ -378,7 +378,7 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
     struct Rec { uint32_t target, doc, kmers; };
     std::vector<Rec> recs;
     std::vector<std::pair<uint32_t, size_t>> blocks;               // (target query, first record) per '*' header
-    std::map<std::string, uint32_t> ref_id;
+    std::unordered_map<std::string, uint32_t> ref_id;
     std::vector<std::string> refs;
     auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
     auto parse_int = [](const char* b, const char* e, uint64_t* out) {
@@ -445,7 +445,12 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
     mb.ref_rank.resize(refs.size());
     for (size_t d = 0; d < refs.size(); ++d) { mb.ref_off[d] = (uint32_t)mb.refs.size(); mb.refs += refs[d]; mb.refs.push_back('\0'); }
     mb.ref_off[refs.size()] = (uint32_t)mb.refs.size();
-    { uint32_t r = 0; for (auto& kv : ref_id) mb.ref_rank[kv.second] = r++; }          // std::map iterates in name order
+    {   // rank of every reference name inside the batch (names are distinct here: they were interned)
+        std::vector<uint32_t> order(refs.size());
+        for (size_t d = 0; d < refs.size(); ++d) order[d] = (uint32_t)d;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return refs[x] < refs[y]; });
+        for (size_t i = 0; i < order.size(); ++i) mb.ref_rank[order[i]] = (uint32_t)i;
+    }
     for (size_t k = 0; k < blocks.size(); ++k) {
         const uint32_t target = blocks[k].first;
         const size_t a = blocks[k].second, b2 = k + 1 < blocks.size() ? blocks[k + 1].second : recs.size();

@@ -123,12 +123,19 @@ def filter_files_native(query_path, match_paths, keep, out_bin, log=None):
     if q.count()[0] != sum(1 for ln in fasta.split(b"\n") if ln[:1] in (b">", b"@")):
         return False                               # records without sequence, FASTQ ...: the general reader handles them
     m = pm.Merge(q, keep)
-    for path in match_paths:
+
+    def one(path):
         batch = os.path.basename(str(path)).split("____")[0]
-        if log:
-            print(f"Translating matches {path}", file=log)
         with (gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")) as f:
-            m.add_text(batch, f.read())
+            m.add_text(batch, f.read())           # inflating and parsing run outside the GIL; the merge serialises its own part
+
+    if log:
+        for path in match_paths:
+            print(f"Translating matches {path}", file=log)
+    # the result does not depend on the order of the files (the best n + ties of a union), so they are read in parallel
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)), len(match_paths)))) as ex:
+        list(ex.map(one, match_paths))
     out_bin.write(m.emit())
     return True
 

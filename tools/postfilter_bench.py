@@ -2,7 +2,10 @@
 """Host-side rows a8 / f1: native text formatting + post-filter (pm_format_hits) and native
 04_filter merge (pm_merge_*) against the Python line loops that mirror the reference's
 scripts/postprocess_cobs.py and scripts/filter_queries.py, on the same synthetic 03_match
-content (Q queries x B batches, H hits per (query, batch))."""
+content (Q queries x B batches, H hits per (query, batch)).  With a checkout of the reference as second
+argument (build container only) the reference's own scripts/postprocess_cobs.py is timed on the same text.
+
+    python3 tools/postfilter_bench.py [Q] [/root/reference]"""
 import gzip
 import io
 import os
@@ -38,6 +41,14 @@ print(f"{Q} queries x {B} batches x {H} hits: cobs text {sum(map(len, plain)) / 
 print(f"  native format (plain)            {t_plain:7.2f} s")
 print(f"  native format + post-filter n=10 {t_fused:7.2f} s")
 print(f"  Python post-filter line loop     {t_py:7.2f} s   (+ the text has to exist first)")
+if len(sys.argv) > 2:
+    import subprocess
+    script = os.path.join(sys.argv[2], "scripts", "postprocess_cobs.py")
+    t = time.time()
+    ref = [subprocess.run([sys.executable, script, "-n", "10"], input=x, capture_output=True, check=True).stdout for x in plain]
+    t_ref = time.time() - t
+    assert all(a == b for a, b in zip(fused, ref)), "the reference's post-filter prints something else"
+    print(f"  reference postprocess_cobs.py    {t_ref:7.2f} s   (same bytes as the fused native form)")
 
 d = tempfile.mkdtemp()
 files = []

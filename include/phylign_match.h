@@ -258,6 +258,13 @@ int  pm_format_hits(const pm_index_t* idx, const pm_queries_t* q,
 int  pm_format_hits_limit(const pm_index_t* idx, const pm_queries_t* q,
                           const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
                           uint64_t limit, char** text, size_t* len);
+/* The 03_match file of one batch in one call: pm_format_hits(nb_best_hits) deflated like `gzip --fast` (level 1; as
+ * consecutive gzip members, built on several threads) and written to `path` via "<path>.tmp" + rename -- what
+ * `... | postprocess_cobs.py -n N | gzip --fast > intermediate/03_match/<batch>____<qfile>.gz` leaves (Snakefile:463-469).
+ * *text_bytes / *gz_bytes (optional): sizes before / after compression. */
+int  pm_format_hits_gz(const pm_index_t* idx, const pm_queries_t* q,
+                       const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits,
+                       const char* path, int level, uint64_t* text_bytes, uint64_t* gz_bytes);
 /* one-shot: what `cobs query -i INDEX -f FASTA -t T` prints */
 int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
                    double threshold, int64_t nb_best_hits, char** text, size_t* len);

@@ -1,6 +1,7 @@
 // pm_text.cpp -- cobs result text (a7), the fused post-filter (a8) and the native
 // 04_filter merge: host work, no GPU needed.
 #include "pm_host.h"
+#include <zlib.h>
 
 // --------------------------------------------------------------------- text
 // cobs stdout grammar (witnesses: scripts/postprocess_cobs.py:23-26, :10-13;
@@ -101,9 +102,10 @@ extern "C" int pm_format_hits_limit(const pm_index_t* ix, const pm_queries_t* q,
     return format_impl(ix, q, hits, n_hits, slot, -1, limit, text, len);
 }
 
-static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
-                       int64_t nb_best, uint64_t limit, char** text, size_t* len) {
-    if (!ix || !q || (!hits && n_hits) || !text || !len) return fail(PM_EINVAL, "bad argument");
+// the text in consecutive pieces (one per formatting thread, each ending on a line boundary)
+static int format_parts(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                        int64_t nb_best, uint64_t limit, std::vector<std::string>& parts) {
+    if (!ix || !q || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
     const size_t nq = q->headers.size();
     // records as pm_result_hits_* deliver them are already in line order: the slot's records are
     // one contiguous slice; anything else (gathered, hand-made) is copied and ordered first
@@ -125,7 +127,8 @@ static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit
     // thread spends seconds per batch here, scripts/postprocess_cobs.py far more)
     size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), (nq + n_mine / 8) / 4096);
     if (nt < 1) nt = 1;
-    std::vector<std::string> parts(nt), errs(nt);
+    parts.assign(nt, std::string());
+    std::vector<std::string> errs(nt);
     std::vector<int> rcs(nt, PM_OK);
     // split by records + queries so that long hit lists spread evenly
     std::vector<size_t> cutq(nt + 1, nq);
@@ -154,6 +157,14 @@ static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit
     }
     for (size_t t = 0; t < nt; ++t)
         if (rcs[t] != PM_OK) return fail(rcs[t], "%s", errs[t].c_str());      // the first failing query range, as a serial pass would report
+    return PM_OK;
+}
+
+static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
+                       int64_t nb_best, uint64_t limit, char** text, size_t* len) {
+    if (!text || !len) return fail(PM_EINVAL, "bad argument");
+    std::vector<std::string> parts;
+    { int rc = format_parts(ix, q, hits, n_hits, slot, nb_best, limit, parts); if (rc) return rc; }
     size_t total = 0;
     for (auto& s2 : parts) total += s2.size();
     char* buf = (char*)malloc(total + 1);
@@ -162,6 +173,86 @@ static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit
     for (auto& s2 : parts) { memcpy(buf + o, s2.data(), s2.size()); o += s2.size(); }
     buf[total] = 0;
     *text = buf; *len = total;
+    return PM_OK;
+}
+
+// The 03_match FILE of one batch in one call: what `run_cobs_streaming.sh ... | postprocess_cobs.py -n N | gzip --fast >
+// <batch>____<qfile>.gz` leaves on disk (Snakefile:463-469).  The text is formatted on several threads (as above), cut at
+// line boundaries into chunks of ~4 MiB that are deflated in parallel as consecutive gzip MEMBERS (a multi-member file is
+// a valid gzip stream: `gzip -dc`, xopen and Python's gzip decode it to the same bytes -- scripts/filter_queries.py:46
+// reads through xopen), and written to "<path>.tmp" + rename.  Nothing of it passes through the caller.
+extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
+                                 uint32_t slot, int64_t nb_best, const char* path, int level,
+                                 uint64_t* text_bytes, uint64_t* gz_bytes) {
+    if (!path || level < 0 || level > 9) return fail(PM_EINVAL, "bad argument");
+    std::vector<std::string> parts;
+    { int rc = format_parts(ix, q, hits, n_hits, slot, nb_best, 0, parts); if (rc) return rc; }
+    struct Chunk { const char* p; size_t n; };
+    std::vector<Chunk> chunks;
+    constexpr size_t kChunk = 4u << 20;
+    uint64_t total = 0;
+    for (const std::string& s2 : parts) {
+        total += s2.size();
+        size_t o = 0;
+        while (o < s2.size()) {
+            size_t e = std::min(s2.size(), o + kChunk);
+            if (e < s2.size()) {
+                const void* nl = memchr(s2.data() + e, '\n', s2.size() - e);
+                e = nl ? (size_t)((const char*)nl - s2.data()) + 1 : s2.size();
+            }
+            chunks.push_back({s2.data() + o, e - o});
+            o = e;
+        }
+    }
+    if (chunks.empty()) chunks.push_back({"", 0});                    // an empty text is one empty member
+    std::vector<std::string> members(chunks.size());
+    std::vector<int> zrc(chunks.size(), Z_OK);
+    std::atomic<size_t> next{0};
+    auto deflate_worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= chunks.size()) return;
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            int rc = deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);      // 15 + 16: gzip container
+            if (rc != Z_OK) { zrc[i] = rc; continue; }
+            std::string& out = members[i];
+            out.resize(deflateBound(&z, (uLong)chunks[i].n) + 64);
+            z.next_in = (Bytef*)const_cast<char*>(chunks[i].p); z.avail_in = (uInt)chunks[i].n;
+            z.next_out = (Bytef*)&out[0]; z.avail_out = (uInt)out.size();
+            rc = deflate(&z, Z_FINISH);
+            if (rc != Z_STREAM_END) zrc[i] = rc == Z_OK ? Z_BUF_ERROR : rc;
+            else out.resize(z.total_out);
+            deflateEnd(&z);
+        }
+    };
+    {
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), chunks.size()));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; ++t) th.emplace_back(deflate_worker);
+        deflate_worker();
+        for (auto& x : th) x.join();
+    }
+    for (int rc : zrc) if (rc != Z_OK) return fail(PM_EIO, "zlib deflate failed (%d)", rc);
+    const std::string tmp = std::string(path) + ".tmp";
+    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(PM_EIO, "cannot create '%s': %s", tmp.c_str(), strerror(errno));
+    uint64_t gz = 0;
+    int e = 0;
+    for (const std::string& m2 : members) {
+        const char* p2 = m2.data(); size_t left = m2.size();
+        while (left && !e) {
+            ssize_t w = write(fd, p2, left);
+            if (w < 0) { if (errno == EINTR) continue; e = errno; break; }
+            p2 += w; left -= (size_t)w;
+        }
+        gz += m2.size();
+    }
+    if (close(fd) != 0 && !e) e = errno;
+    if (e) { (void)unlink(tmp.c_str()); return fail(PM_EIO, "writing '%s': %s", tmp.c_str(), strerror(e)); }
+    if (rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
+    if (text_bytes) *text_bytes = total;
+    if (gz_bytes) *gz_bytes = gz;
     return PM_OK;
 }
 

@@ -237,11 +237,17 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             b = batches[pos]
             part = hits[cut[i]:cut[i + 1]]
             ta = time.perf_counter()
-            text = pm.format_hits(ix, queries, part, slot=i, nb_best_hits=nb)
-            tb = time.perf_counter()
-            # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
-            pgzip.write(os.path.join(out_dir, f"{b}____{qfile}.gz"), text, level=1, pool=deflaters)
-            tc = tc0 = time.perf_counter()
+            if keep_texts is None:
+                # records -> post-filtered text -> `gzip --fast` members -> file, all inside the library (Snakefile:463-469)
+                pm.format_hits_gz(ix, queries, part, os.path.join(out_dir, f"{b}____{qfile}.gz"), slot=i, nb_best_hits=nb, level=1)
+                text = None
+                tb = tc = tc0 = time.perf_counter()
+            else:
+                text = pm.format_hits(ix, queries, part, slot=i, nb_best_hits=nb)
+                tb = time.perf_counter()
+                # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
+                pgzip.write(os.path.join(out_dir, f"{b}____{qfile}.gz"), text, level=1, pool=deflaters)
+                tc = tc0 = time.perf_counter()
             td = tc
             if merge is not None:
                 with merge_mu:                           # the library serialises adds anyway; the ordinal of the add is the export's slot
@@ -298,6 +304,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
               "match_only_s": round(acc["match_only_s"], 4), "gpu_wait_s": round(acc["gpu_wait_s"], 4),
               "d2h_s": round(acc["d2h_s"], 4), "load_s_thread_sum": round(acc["load_s"], 3),
               "format_s_thread_sum": round(acc["format_s"], 3), "gzip_s_thread_sum": round(acc["gzip_s"], 3),
+              "format_and_gzip_in_library": keep_texts is None,
               "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
               "per_group": group_rows, "merge_order": merge_order}
     return report, merge

@@ -835,3 +835,45 @@ def test_filter_readers_on_edge_cases_captured_from_the_reference(case):
             m.add_text(case, text)
         with pytest.raises(Exception):
             F.filter_files(qfa, [path], 3, io.StringIO())
+
+
+@pytest.mark.parametrize("case", ["ties_large", "random_mid", "zero_hits"])
+def test_native_match_file_writer(case, tmp_path):
+    """pm_format_hits_gz: the 03_match file of a batch in one call -- its gunzipped bytes are pm_format_hits' (= the
+    reference post-filter's, by the fixtures), `gzip -dc` reads the multi-member file, no .tmp is left"""
+    import gzip
+    from phylign_amd import _lib as pm
+    base = os.path.join(GOLD, "postprocess", case)
+    fasta, names, hits = _structured(open(base + ".in").read())
+    q = pm.Queries(fasta, term_size=31)
+    ix = pm.Index.from_names(names)
+    for n in (-1, 2, 100):
+        want = pm.format_hits(ix, q, hits, slot=0, nb_best_hits=n)
+        path = tmp_path / f"{case}.{n}.gz"
+        tb, zb = pm.format_hits_gz(ix, q, hits, str(path), slot=0, nb_best_hits=n, level=1)
+        assert tb == len(want) and zb == os.path.getsize(path)
+        assert gzip.open(path, "rb").read() == want
+        assert subprocess.run(["gzip", "-dc", str(path)], capture_output=True, check=True).stdout == want
+    assert not list(tmp_path.glob("*.tmp"))
+    with pytest.raises(pm.PMError):
+        pm.format_hits_gz(ix, q, hits, str(tmp_path / "no_such_dir" / "x.gz"))
+
+
+def test_native_match_file_writer_many_members(tmp_path):
+    """a text of several 4 MiB chunks: members are cut at line boundaries and decode to the same bytes"""
+    import gzip
+    from phylign_amd import _lib as pm
+    n = 400_000
+    fasta = b"".join(b">query_number_%07d with a comment\nACGTACGTACGTACGTACGTACGTACGTACGTACG\n" % i for i in range(n))
+    q = pm.Queries(fasta, term_size=31)
+    ix = pm.Index.from_names([f"{i:05x}_REF{i:04d}" for i in range(300)])
+    rng = np.random.default_rng(2)
+    recs = np.zeros(n // 2, dtype=pm.HIT_DTYPE)
+    recs["query"] = np.sort(rng.integers(0, n, n // 2)); recs["doc"] = rng.integers(0, 300, n // 2); recs["score"] = 5
+    pm.sort_hits(recs)
+    want = pm.format_hits(ix, q, recs, slot=0, nb_best_hits=100)
+    assert len(want) > 3 * (4 << 20)
+    tb, zb = pm.format_hits_gz(ix, q, recs, str(tmp_path / "big.gz"), slot=0, nb_best_hits=100)
+    raw = open(tmp_path / "big.gz", "rb").read()
+    assert raw.count(b"\x1f\x8b\x08") >= 4 and tb == len(want) and zb == len(raw)
+    assert gzip.decompress(raw) == want

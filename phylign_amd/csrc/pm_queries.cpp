@@ -67,21 +67,19 @@ static int finish_queries(pm_queries* q) {
     return PM_OK;
 }
 
-extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
-    if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
-    pm_queries* q = new pm_queries();
-    q->k = term_size;
+// records of fasta[begin, end) by the cobs CLI's rules into q (a scratch object when several threads parse a file);
+// have_any: a header line has been seen before `begin` (false only at the start of the file)
+static int parse_cobs_range(pm_queries* q, const char* fasta, size_t begin, size_t end, bool have_any) {
     std::string cur_hdr, cur_seq;
-    bool have_any = false;
     int rc = PM_OK;
     auto flush = [&]() -> int {
         if (cur_seq.empty()) return PM_OK;
         return add_record(q, cur_hdr, cur_seq, !have_any);
     };
-    size_t p = 0;
-    while (p < len && rc == PM_OK) {
-        const char* nl = (const char*)memchr(fasta + p, '\n', len - p);
-        size_t ll = nl ? (size_t)(nl - (fasta + p)) : len - p;
+    size_t p = begin;
+    while (p < end && rc == PM_OK) {
+        const char* nl = (const char*)memchr(fasta + p, '\n', end - p);
+        size_t ll = nl ? (size_t)(nl - (fasta + p)) : end - p;
         const char* line = fasta + p;
         p += ll + (nl ? 1 : 0);
         if (ll == 0) continue;
@@ -95,6 +93,63 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
         }
     }
     if (rc == PM_OK) rc = flush();
+    return rc;
+}
+
+extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
+    if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
+    pm_queries* q = new pm_queries();
+    q->k = term_size;
+    int rc = PM_OK;
+    // a million reads are 160 MB of text: the file is cut at header lines and the pieces are parsed on several threads
+    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), len / (8u << 20));
+    std::vector<size_t> cut{0};
+    for (size_t t = 1; t < nt; ++t) {
+        size_t p = std::max(len * t / nt, cut.back());
+        size_t b = len;
+        while (p < len) {                                      // next line that starts a record
+            const char* nl = (const char*)memchr(fasta + p, '\n', len - p);
+            if (!nl) break;
+            p = (size_t)(nl - fasta) + 1;
+            if (p < len && (fasta[p] == '>' || fasta[p] == ';')) { b = p; break; }
+        }
+        if (b > cut.back() && b < len) cut.push_back(b);
+    }
+    cut.push_back(len);
+    if (cut.size() <= 2) {
+        rc = parse_cobs_range(q, fasta, 0, len, false);
+    } else {
+        const size_t n = cut.size() - 1;
+        std::vector<pm_queries> part(n);
+        std::vector<int> rcs(n, PM_OK);
+        std::vector<std::string> errs(n);
+        auto work = [&](size_t t) {
+            part[t].k = term_size;
+            rcs[t] = parse_cobs_range(&part[t], fasta, cut[t], cut[t + 1], t > 0);
+            if (rcs[t] != PM_OK) errs[t] = pm_last_error();     // the message is thread-local: carry it to the caller's thread
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        size_t total_seq = 0, total_rec = 0;
+        for (size_t t = 0; t < n && rc == PM_OK; ++t) {
+            if (rcs[t] != PM_OK) rc = fail(rcs[t], "%s", errs[t].c_str());      // the first failing record in file order
+            total_seq += part[t].seqs.size(); total_rec += part[t].headers.size();
+        }
+        if (rc == PM_OK) {
+            q->seqs.reserve(total_seq);
+            q->headers.reserve(total_rec); q->headerless.reserve(total_rec); q->n_terms.reserve(total_rec); q->seq_off.reserve(total_rec + 1);
+            for (size_t t = 0; t < n; ++t) {
+                const uint64_t base = q->seqs.size();
+                for (uint64_t o : part[t].seq_off) q->seq_off.push_back(base + o);
+                q->seqs += part[t].seqs;
+                for (auto& h : part[t].headers) q->headers.push_back(std::move(h));
+                q->headerless.insert(q->headerless.end(), part[t].headerless.begin(), part[t].headerless.end());
+                q->n_terms.insert(q->n_terms.end(), part[t].n_terms.begin(), part[t].n_terms.end());
+            }
+        }
+    }
     if (rc == PM_OK) rc = finish_queries(q);
     if (rc != PM_OK) { delete q; return rc; }
     *out = q;

@@ -877,3 +877,35 @@ def test_native_match_file_writer_many_members(tmp_path):
     raw = open(tmp_path / "big.gz", "rb").read()
     assert raw.count(b"\x1f\x8b\x08") >= 4 and tb == len(want) and zb == len(raw)
     assert gzip.decompress(raw) == want
+
+
+def test_large_query_file_is_parsed_in_pieces_with_the_same_result():
+    """files of 16 MB and more are cut at header lines and parsed on several threads: same records as the small-file
+    path (multi-line records, ';' headers, a headerless first record), the first error in file order is the one reported"""
+    from phylign_amd import _lib as pm
+    rng = np.random.default_rng(9)
+    n = 120_000
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 150))]
+    recs = []
+    for i in range(n):
+        s = seqs[i].tobytes()
+        if i % 1000 == 0:
+            recs.append(b";semi %d\n" % i + s[:70] + b"\n" + s[70:] + b"\n\n")
+        else:
+            recs.append(b">r%d some words\n" % i + s + b"\n")
+    big = b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTA\n" + b"".join(recs)
+    assert len(big) > (16 << 20)
+    q = pm.Queries(big)
+    assert q.count()[0] == n + 1
+    want = b"\nACGTACGTACGTACGTACGTACGTACGTACGTACGTA\n" + b"".join(       # (a record without header line has an empty one)
+        (b">semi %d\n" % i if i % 1000 == 0 else b">r%d some words\n" % i) + seqs[i].tobytes() + b"\n" for i in range(n))
+    assert q.fasta() == want
+    small = [pm.Queries(b"".join(recs[a:a + 1000])) for a in (0, 57_000, 119_000)]        # the same records through the one-piece path
+    assert small[1].fasta() == b"".join(
+        (b">semi %d\n" % i if i % 1000 == 0 else b">r%d some words\n" % i) + seqs[i].tobytes() + b"\n" for i in range(57_000, 58_000))
+    bad = recs[:]
+    bad[40_000] = b">early\nACGTNNACGTACGTACGTACGTACGTACGTACGTACGT\n"
+    bad[110_000] = b">late\nACG\n"
+    with pytest.raises(pm.PMError) as e:
+        pm.Queries(b"".join(bad))
+    assert e.value.code == -6 and "early" in str(e.value)

@@ -272,6 +272,9 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     resident = bool(getattr(source, "resident", False))
     if resident:                                        # nothing to decode: every batch is ready, no loader threads
         ready.extend((pos, source.load(batches[pos]), 0.0) for pos in mine)
+        if max_group <= 0 and len(mine) >= 16:
+            # two halves instead of one group: the host half of the first (text, gzip, merge) overlaps the scan of the second
+            max_group = (len(mine) + 1) // 2
     with ThreadPoolExecutor(max_workers=max(1, loaders)) as pool:
         futures = [] if resident else [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
         try:

@@ -53,9 +53,14 @@ def cycle(n):
         r.free()
 
 
-cycle(4)
-f0 = pm.device_info()["hbm_free"]; r0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-cycle(30)
-f1 = pm.device_info()["hbm_free"]; r1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-print("hbm_free delta MB", (f0 - f1) / 1e6, "maxrss delta MB", (r1 - r0) / 1e3)
+def rss_mb():
+    return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+
+
+cycle(6)
+f0, r0 = pm.device_info()["hbm_free"], rss_mb()
+for rnd in range(3):
+    cycle(20)
+    print(f"after {20 * (rnd + 1)} more cycles: hbm_free delta MB {(f0 - pm.device_info()['hbm_free']) / 1e6:.1f}, "
+          f"rss delta MB {rss_mb() - r0:.1f} (rss {rss_mb():.0f} MB, maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e3:.0f} MB)", flush=True)
 shutil.rmtree(tmp)

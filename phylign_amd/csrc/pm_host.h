@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <functional>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -142,6 +144,12 @@ struct pm_queries {
     uint64_t epoch = 0;
 };
 
+// pm_runtime.cpp: fn(0) ... fn(n - 1) on the library's persistent worker threads (and the caller's); returns when all
+// are done.  Host-side work (text formatting, deflate, FASTA emit, query parsing) used to start its own std::threads per
+// call: thousands of short-lived threads leave glibc one malloc arena each (RSS grew by ~7 MB per stage run on a 256-CPU
+// box, tools/leak_check_stage.py); pooled threads keep their arenas.  fn must not call parallel_for itself.
+void parallel_for(size_t n, const std::function<void(size_t)>& fn);
+size_t parallel_width();                    // worker threads + the caller (<= 16)
 // pm_index.cpp: pooled staging buffers of the parallel file loader (released by pm_shutdown)
 void release_stage_pool();
 // pm_queries.cpp: HBM copies of a query set on first use; device hashes per (canonicalize, num_hashes)

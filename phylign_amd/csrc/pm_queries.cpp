@@ -102,7 +102,7 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
     q->k = term_size;
     int rc = PM_OK;
     // a million reads are 160 MB of text: the file is cut at header lines and the pieces are parsed on several threads
-    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), len / (8u << 20));
+    size_t nt = std::min<size_t>(parallel_width(), len / (8u << 20));
     std::vector<size_t> cut{0};
     for (size_t t = 1; t < nt; ++t) {
         size_t p = std::max(len * t / nt, cut.back());
@@ -128,10 +128,7 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
             rcs[t] = parse_cobs_range(&part[t], fasta, cut[t], cut[t + 1], t > 0);
             if (rcs[t] != PM_OK) errs[t] = pm_last_error();     // the message is thread-local: carry it to the caller's thread
         };
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < n; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
+        parallel_for(n, work);
         size_t total_seq = 0, total_rec = 0;
         for (size_t t = 0; t < n && rc == PM_OK; ++t) {
             if (rcs[t] != PM_OK) rc = fail(rcs[t], "%s", errs[t].c_str());      // the first failing record in file order

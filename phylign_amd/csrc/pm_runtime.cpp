@@ -23,6 +23,71 @@ uint32_t g_single_launch = 0;
 uint32_t g_wide_query = 0;
 uint32_t g_wq_split = 0;
 
+// ------------------------------------------------------------- worker pool
+namespace {
+struct Job { const std::function<void(size_t)>* fn; size_t n; std::atomic<size_t> next{0}, done{0}; };
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> threads;
+    std::vector<Job*> jobs;                   // jobs with unclaimed items
+    bool stop = false;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !jobs.empty(); });
+            if (stop) return;
+            Job* j = jobs.front();                          // picked and claimed under the lock: the job is alive
+            const size_t n = j->n;
+            const size_t i = j->next.fetch_add(1);
+            if (i + 1 >= n) jobs.erase(jobs.begin());       // nothing left to claim (or this was the last item)
+            if (i >= n) continue;
+            lk.unlock();
+            (*j->fn)(i);
+            lk.lock();
+            // the owner may destroy the job as soon as it sees done == n: it checks under this lock, and `j` is not touched after the add
+            if (j->done.fetch_add(1) + 1 == n) cv_done.notify_all();
+        }
+    }
+    void ensure(size_t want) {
+        std::lock_guard<std::mutex> lk(mu);
+        while (threads.size() < want) threads.emplace_back([this] { worker(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
+Pool& pool() { static Pool* p = new Pool(); return *p; }      // never destroyed: worker threads may outlive static destructors
+}  // namespace
+
+size_t parallel_width() {
+    const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+    return std::min<size_t>(hw, 16);
+}
+void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+    if (n == 0) return;
+    if (n == 1) { fn(0); return; }
+    Pool& p = pool();
+    p.ensure(parallel_width() - 1);
+    Job job; job.fn = &fn; job.n = n;
+    {
+        std::lock_guard<std::mutex> lk(p.mu);
+        p.jobs.push_back(&job);
+    }
+    p.cv.notify_all();
+    for (;;) {                                 // the caller works too
+        const size_t i = job.next.fetch_add(1);
+        if (i >= n) break;
+        fn(i);
+        job.done.fetch_add(1);
+    }
+    std::unique_lock<std::mutex> lk(p.mu);
+    for (auto it = p.jobs.begin(); it != p.jobs.end(); ++it) if (*it == &job) { p.jobs.erase(it); break; }   // all items are claimed
+    p.cv_done.wait(lk, [&] { return job.done.load() >= n; });
+}
+
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
 

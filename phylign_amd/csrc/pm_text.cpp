@@ -125,7 +125,7 @@ static int format_parts(const pm_index_t* ix, const pm_queries_t* q, const pm_hi
         return fail(PM_EINVAL, "hit record (query %u) out of range for this query set", mine[n_mine - 1].query);
     // query ranges are independent: format them on several host threads (at 1 M queries a single
     // thread spends seconds per batch here, scripts/postprocess_cobs.py far more)
-    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), (nq + n_mine / 8) / 4096);
+    size_t nt = std::min<size_t>(parallel_width(), (nq + n_mine / 8) / 4096);
     if (nt < 1) nt = 1;
     parts.assign(nt, std::string());
     std::vector<std::string> errs(nt);
@@ -148,13 +148,7 @@ static int format_parts(const pm_index_t* ix, const pm_queries_t* q, const pm_hi
         parts[t].reserve((size_t)((double)(n_mine * 28 + nq * 24) / (double)nt * 1.1) + 64);
         rcs[t] = format_query_range(ix, q, mine, n_mine, cutq[t], cutq[t + 1], nb_best, limit, parts[t], errs[t]);
     };
-    if (nt == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
+    parallel_for(nt, work);
     for (size_t t = 0; t < nt; ++t)
         if (rcs[t] != PM_OK) return fail(rcs[t], "%s", errs[t].c_str());      // the first failing query range, as a serial pass would report
     return PM_OK;
@@ -207,15 +201,12 @@ extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, co
     if (chunks.empty()) chunks.push_back({"", 0});                    // an empty text is one empty member
     std::vector<std::string> members(chunks.size());
     std::vector<int> zrc(chunks.size(), Z_OK);
-    std::atomic<size_t> next{0};
-    auto deflate_worker = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= chunks.size()) return;
+    auto deflate_one = [&](size_t i) {
+        {
             z_stream z;
             memset(&z, 0, sizeof z);
             int rc = deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);      // 15 + 16: gzip container
-            if (rc != Z_OK) { zrc[i] = rc; continue; }
+            if (rc != Z_OK) { zrc[i] = rc; return; }
             std::string& out = members[i];
             out.resize(deflateBound(&z, (uLong)chunks[i].n) + 64);
             z.next_in = (Bytef*)const_cast<char*>(chunks[i].p); z.avail_in = (uInt)chunks[i].n;
@@ -226,13 +217,7 @@ extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, co
             deflateEnd(&z);
         }
     };
-    {
-        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), chunks.size()));
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; ++t) th.emplace_back(deflate_worker);
-        deflate_worker();
-        for (auto& x : th) x.join();
-    }
+    parallel_for(chunks.size(), deflate_one);
     for (int rc : zrc) if (rc != Z_OK) return fail(PM_EIO, "zlib deflate failed (%d)", rc);
     const std::string tmp = std::string(path) + ".tmp";
     int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -591,7 +576,7 @@ static void merge_emit_pieces(const pm_merge* m, std::vector<std::string>& parts
             recs.push_back(rec);
         }
     }
-    size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), recs.size() / 8192);
+    size_t nt = std::min<size_t>(parallel_width(), recs.size() / 8192);
     if (nt < 1) nt = 1;
     parts.assign(nt, std::string());
     auto work = [&](size_t t) {
@@ -615,11 +600,7 @@ static void merge_emit_pieces(const pm_merge* m, std::vector<std::string>& parts
             out.push_back('\n');
         }
     };
-    if (nt == 1) { work(0); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
+    parallel_for(nt, work);
 }
 
 extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
@@ -658,12 +639,7 @@ extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_
             p += w; left -= (size_t)w; o += (uint64_t)w;
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < parts.size(); ++t) th.emplace_back(wr, t);
-        wr(0);
-        for (auto& x : th) x.join();
-    }
+    parallel_for(parts.size(), wr);
     int e = 0;
     for (int x : errs) if (x) e = x;
     if (close(fd) != 0 && !e) e = errno;

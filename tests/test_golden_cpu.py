@@ -909,3 +909,42 @@ def test_large_query_file_is_parsed_in_pieces_with_the_same_result():
     with pytest.raises(pm.PMError) as e:
         pm.Queries(b"".join(bad))
     assert e.value.code == -6 and "early" in str(e.value)
+
+
+def test_worker_pool_serves_concurrent_callers(tmp_path):
+    """text formatting, the gz writer, the FASTA emit and the query parser share one persistent worker pool: eight caller
+    threads at once, many rounds, every result equal to the single-caller result"""
+    import gzip
+    import threading
+    from phylign_amd import _lib as pm
+    n = 60_000
+    fasta = b"".join(b">q%06d\nACGTACGTACGTACGTACGTACGTACGTACGTACG\n" % i for i in range(n))
+    q = pm.Queries(fasta, term_size=31)
+    ix = pm.Index.from_names([f"{i:05x}_R{i:03d}" for i in range(200)])
+    rng = np.random.default_rng(6)
+    recs = np.zeros(3 * n, dtype=pm.HIT_DTYPE)
+    recs["query"] = np.repeat(np.arange(n, dtype=np.uint32), 3); recs["doc"] = rng.integers(0, 200, 3 * n); recs["score"] = rng.integers(1, 6, 3 * n)
+    pm.sort_hits(recs)
+    want = pm.format_hits(ix, q, recs, slot=0, nb_best_hits=2)
+    m = pm.Merge(q, 2)
+    m.add("b__01", ix, recs, slot=0, nb_best_hits=2)
+    want_fa = m.emit()
+    errors = []
+
+    def caller(t):
+        try:
+            for r in range(6):
+                assert pm.format_hits(ix, q, recs, slot=0, nb_best_hits=2) == want
+                p = tmp_path / f"t{t}.gz"
+                pm.format_hits_gz(ix, q, recs, str(p), slot=0, nb_best_hits=2)
+                assert gzip.open(p, "rb").read() == want
+                assert m.emit() == want_fa
+                assert pm.Queries(fasta * 6, term_size=31).count()[0] == 6 * n        # 16 MB+: the piecewise parser
+        except Exception as e:                                                       # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(8)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:2]

@@ -50,7 +50,9 @@ def scale_shapes(shapes, rows_divisor):
 # measured scan time per looked-up row by 128-byte lines per row, relative to 400 for a 4-line row
 # (tools/per_batch_cost.py on one MI355X, 12 M lookups per batch, fetch-all scan with non-temporal gathers;
 # profiles/r03/per_batch_cost.tsv): 0.281 / 0.511 / 0.726 / 0.966 ms for 1 / 2 / 3 / 4 lines
-_LINE_COST = {1: 116, 2: 212, 3: 301, 4: 400}
+# plus ~25 units per batch whatever its width: in the fused launches of an 8-way split a rank with more (narrow) batches
+# ran 0.06-0.08 ms per extra batch behind the others (profiles/r03/emulate_scaling.tsv)
+_LINE_COST = {1: 141, 2: 237, 3: 326, 4: 425}
 
 
 def scan_cost(shape):

@@ -82,6 +82,36 @@ def assign_batches(shapes, n_ranks, capacity_bytes=None):
         out[r].append(i)
         load[r] += scan_cost(shapes[i])
         used[r] += shapes[i].index_bytes
+    # greedy LPT leaves the heaviest rank a whole small batch above the others (4 % at 8 ranks x 64 batches): refine by
+    # moving one batch, or exchanging two, between the heaviest rank and any other while that lowers the pair's maximum
+    cost = [scan_cost(s) for s in shapes]
+    nbytes = [s.index_bytes for s in shapes]
+    fits = (lambda r, delta: True) if capacity_bytes is None else (lambda r, delta: used[r] + delta <= capacity_bytes)
+    for _ in range(4 * len(shapes)):
+        a = max(range(n_ranks), key=lambda r: (load[r], -r))
+        best = None                                            # (new pair maximum, b, item of a, item of b or None)
+        for b in range(n_ranks):
+            if b == a:
+                continue
+            for i in out[a]:
+                if fits(b, nbytes[i]):                          # move i: a -> b
+                    m = max(load[a] - cost[i], load[b] + cost[i])
+                    if m < load[a] and (best is None or (m, b, i, -1) < (best[0], best[1], best[2], -1 if best[3] is None else best[3])):
+                        best = (m, b, i, None)
+                for j in out[b]:                                # swap i <-> j
+                    if cost[j] >= cost[i] or not fits(b, nbytes[i] - nbytes[j]) or not fits(a, nbytes[j] - nbytes[i]):
+                        continue
+                    m = max(load[a] - cost[i] + cost[j], load[b] + cost[i] - cost[j])
+                    if m < load[a] and (best is None or (m, b, i, j) < (best[0], best[1], best[2], -1 if best[3] is None else best[3])):
+                        best = (m, b, i, j)
+        if best is None:
+            break
+        _, b, i, j = best
+        out[a].remove(i); out[b].append(i)
+        load[a] -= cost[i]; load[b] += cost[i]; used[a] -= nbytes[i]; used[b] += nbytes[i]
+        if j is not None:
+            out[b].remove(j); out[a].append(j)
+            load[b] -= cost[j]; load[a] += cost[j]; used[b] -= nbytes[j]; used[a] += nbytes[j]
     return [sorted(x) for x in out]
 
 

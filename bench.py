@@ -240,7 +240,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
     if os.environ.get("PM_SINGLE_LAUNCH"):
-        pm.set_option("single_launch", int(os.environ["PM_SINGLE_LAUNCH"]))      # 0 auto, 1 always, 2 never
+        pm.set_option("single_launch", 1)
     if os.environ.get("PM_WIDE_QUERY"):
         pm.set_option("wide_query", int(os.environ["PM_WIDE_QUERY"]))
     if os.environ.get("PM_WQ_SPLIT"):
@@ -300,10 +300,8 @@ def main():
     phase = {"queue": 0.0, "wait": 0.0, "host": 0.0, "gather": 0.0}
 
     def narrow_lines(infs):
-        """128-byte lines one k-mer touches in the batches of the mixed-width launch: rows of at most 256 bytes, or every row
-        when the search is small enough for the library to fuse all widths into that launch (fewer than 24 batches)"""
-        fused = len(infs) < 24 and not os.environ.get("PM_SINGLE_LAUNCH") == "2"
-        return sum(max(1, int(i.stride) // 128) for i in infs if fused or i.stride <= 256)
+        """128-byte lines one k-mer touches in the batches of the mixed-width launch (rows of at most 256 bytes)"""
+        return sum(max(1, int(i.stride) // 128) for i in infs if i.stride <= 256)
 
     # what the step functions below run on; swapped for the l31 and full_shard legs
     cur = {"indexes": indexes, "q": q, "n_terms": n_terms, "rowsum": sum(s.row_bytes for s in shapes),

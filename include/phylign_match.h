@@ -123,9 +123,7 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * through LDS; the threshold bound is off in that form); 1 = always, 2 = never.
  * "wide_query_split" (default 0 = automatic): in that form, how many workgroups share the steps of one query
  * (a dozen chromosome-sized queries would otherwise leave most of the chip idle); 1 = never, n = force n.
- * "single_launch" (default 0 = automatic): 1 = rows of every width up to 1024 B share one launch, 2 = wide and narrow
- * rows always keep their own launches; automatic fuses them when a search covers fewer than 24 batches (the short launches
- * of a rank in a 4- or 8-way split, where a second drain tail is a few per cent of the step). */
+ * "single_launch" (default 0): rows of every width up to 1024 B share one launch. */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);

@@ -160,10 +160,8 @@ int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out);
 extern uint32_t g_threshold_bound;
 // pm_set_option("count_fetched"): the scan also counts the algorithmic bytes it really gathered
 extern uint32_t g_count_fetched;
-// pm_set_option("single_launch"): 0 = automatic (fused when a search covers fewer than kFuseBelowUnits batches), 1 = every row
-// width (up to 1024 B) goes into the mixed-width launch, 2 = never
+// pm_set_option("single_launch"): every row width (up to 1024 B) goes into the mixed-width launch
 extern uint32_t g_single_launch;
-constexpr size_t kFuseBelowUnits = 24;        // automatic single launch below this many batch units in one search
 // pm_set_option("wide_query"): 0 = automatic (few long queries: several lane groups share a query), 1 = always
 // where instantiated (128+ k-mers per query), 2 = never
 extern uint32_t g_wide_query;

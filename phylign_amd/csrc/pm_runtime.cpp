@@ -157,11 +157,7 @@ extern "C" int pm_set_option(const char* name, int64_t value) {
     if (!name) return fail(PM_EINVAL, "bad argument");
     if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "count_fetched") == 0) { g_count_fetched = value ? 1u : 0u; return PM_OK; }
-    if (strcmp(name, "single_launch") == 0) {
-        if (value < 0 || value > 2) return fail(PM_EINVAL, "single_launch takes 0 (auto), 1 (always) or 2 (never)");
-        g_single_launch = (uint32_t)value;
-        return PM_OK;
-    }
+    if (strcmp(name, "single_launch") == 0) { g_single_launch = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "wide_query") == 0) {
         if (value < 0 || value > 2) return fail(PM_EINVAL, "wide_query takes 0 (auto), 1 (always) or 2 (never)");
         g_wide_query = (uint32_t)value;

@@ -179,14 +179,10 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     // Narrow rows (fewer than 32 lanes, i.e. at most 256 bytes) of all widths share one
     // mixed-width launch (g = 0): each of them is short, and separate launches would pay
     // one drain tail per width class.
-    // "single_launch": 1 = rows of every width (up to 1024 B) share the mixed-width launch, 2 = never, 0 = automatic: when the
-    // search covers few batches (a rank of a 4- or 8-way split) the launches are short and a second drain tail is a few per cent
-    // of the step, so they are fused; with many batches the wide and the narrow rows keep their own launches
-    const bool fuse_all = g_single_launch == 1 || (g_single_launch == 0 && units.size() < kFuseBelowUnits);
     std::vector<Group> groups;
     for (size_t u = 0; u < units.size(); ++u) {
         const pm_index* ix = units[u].ix;
-        const int key = (ix->slabs == 1 && (ix->g < 32 || fuse_all)) ? 0 : ix->g;
+        const int key = (ix->slabs == 1 && (ix->g < 32 || g_single_launch)) ? 0 : ix->g;
         Group* gp = nullptr;
         if (ix->slabs == 1)
             for (auto& g : groups)

@@ -396,7 +396,6 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
     ixs = [pm.Index.load_mem(c[0]) for c in cases]
     assert len({ix.info.stride for ix in ixs}) >= 7
     q = pm.Queries(fasta)
-    pm.set_option("single_launch", 2)                     # wide rows keep their own launch (automatic would fuse 9 batches)
     for thr in (0.7, 0.3):
         res = pm.search(ixs, q, thr, slot_base=5)
         kernels = [L["kernel"] for L in res.launches()]
@@ -405,12 +404,3 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
         hits = res.hits()
         for s, (index, _, _) in enumerate(cases):
             assert pm.format_hits(ixs[s], q, hits, slot=5 + s) == oracle.query_file(index, fasta, thr), shapes[s]
-        # automatic (fewer than 24 batches: one launch for every width up to 1024 B) and forced fusion: same records
-        for mode in (0, 1):
-            pm.set_option("single_launch", mode)
-            res2 = pm.search(ixs, q, thr, slot_base=5)
-            k2 = [L["kernel"] for L in res2.launches()]
-            assert not any("G=32" in k for k in k2) and any("G=mixed" in k for k in k2)
-            assert np.array_equal(res2.hits(), hits)
-        pm.set_option("single_launch", 2)
-    pm.set_option("single_launch", 0)

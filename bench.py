@@ -239,7 +239,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
-    if os.environ.get("PM_SINGLE_LAUNCH"):
+    if os.environ.get("PM_SINGLE_LAUNCH", "0") not in ("", "0"):
         pm.set_option("single_launch", 1)
     if os.environ.get("PM_WIDE_QUERY"):
         pm.set_option("wide_query", int(os.environ["PM_WIDE_QUERY"]))

@@ -45,24 +45,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def effective_cpus():
-    """CPUs this process may really use: the scheduler affinity, capped by the cgroup CPU quota
-    (the GPU box shows 256 logical CPUs but grants the job a 16-CPU quota: 256 threads would
-    only be throttled)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
-        if quota != "max":
-            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
-    except Exception:
-        try:
-            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
-            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota > 0:
-                n = min(n, max(1, int(np.ceil(quota / period))))
-        except Exception:
-            pass
-    return max(1, n)
+from phylign_amd.sysinfo import effective_cpus  # noqa: E402
 
 
 def host_memory_gb():

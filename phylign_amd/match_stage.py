@@ -334,7 +334,9 @@ def main(argv=None):
     ap.add_argument("--threshold", type=float, default=0.7)          # config.yaml:20
     ap.add_argument("--nb-best-hits", type=int, default=100)         # config.yaml:23
     ap.add_argument("--filter-out", default=None)
-    ap.add_argument("--loaders", type=int, default=4, help="concurrent xz decoders per rank")
+    ap.add_argument("--loaders", type=int, default=0,
+                    help="concurrent xz decoders per rank (0 = the CPUs the job may use minus 4, at least 4, at most 16: one "
+                         "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for)")
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
     ap.add_argument("--kmer-size", type=int, default=31, help="k of the indexes (31 for the 661k collection); every batch's header is checked against it")
     ap.add_argument("--max-group", type=int, default=0, help="most batches fused into one search (0 = every resident batch)")
@@ -388,6 +390,9 @@ def main(argv=None):
         fasta = f.read()
     queries = pm.Queries(fasta, term_size=args.kmer_size, normalise=args.raw_queries)   # checked against every batch's header
     budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else None
+    if args.loaders <= 0:
+        from .sysinfo import effective_cpus
+        args.loaders = max(4, min(16, effective_cpus() - 4))
     report, merge = run_stage(pm, batches, mine, source, queries, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                               want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
                               max_group=args.max_group, kmer_size=args.kmer_size)

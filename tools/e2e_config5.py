@@ -17,7 +17,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np  # noqa: E402
 from phylign_amd import _lib as pm  # noqa: E402
 from phylign_amd import match_stage as MS  # noqa: E402
 from phylign_amd import workload as W  # noqa: E402

@@ -160,3 +160,36 @@ def test_eight_way_partition_of_config3_is_balanced_on_measured_batch_times():
         for mode in (0, 1):
             loads = [sum(cost[shapes[i].batch][mode] for i in p) for p in parts]
             assert max(loads) / (sum(loads) / n) <= 1.05, (n, mode, loads)
+
+
+def test_assign_batches_invariants_on_random_collections():
+    """every batch on exactly one rank, capacity respected, never worse than plain LPT's maximum, deterministic"""
+    import numpy as np
+    from phylign_amd import workload as W
+    rng = np.random.default_rng(12)
+    full = W.select("full")
+    for trial in range(40):
+        k = int(rng.integers(1, 120))
+        shapes = [full[i] for i in rng.choice(len(full), size=k, replace=False)]
+        n = int(rng.integers(1, 10))
+        cap = None if trial % 3 else int(sum(s.index_bytes for s in shapes) / n * 1.6) + max(s.index_bytes for s in shapes)
+        parts = W.assign_batches(shapes, n, capacity_bytes=cap)
+        assert sorted(i for p in parts for i in p) == list(range(k)) and len(parts) == n
+        assert parts == W.assign_batches(shapes, n, capacity_bytes=cap)
+        if cap is not None:
+            assert all(sum(shapes[i].index_bytes for i in p) <= cap for p in parts)
+        loads = [sum(W.scan_cost(shapes[i]) for i in p) for p in parts]
+        # plain greedy LPT for comparison
+        order = sorted(range(k), key=lambda i: (-W.scan_cost(shapes[i]), -shapes[i].index_bytes, i))
+        lpt = [0] * n
+        for i in order:
+            lpt[min(range(n), key=lambda r: (lpt[r], r))] += W.scan_cost(shapes[i])
+        if cap is None:
+            assert max(loads) <= max(lpt)
+
+
+def test_effective_cpus_is_positive_and_bounded():
+    import os
+    from phylign_amd.sysinfo import effective_cpus
+    n = effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)

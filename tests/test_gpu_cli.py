@@ -363,7 +363,7 @@ def test_resident_index_server_evicts_under_budget(pm, oracle, tmp_path):
 
 def test_server_keeps_serving_during_a_cold_load_and_fuses_concurrent_jobs(pm, oracle, tmp_path):
     """what 305 per-batch Snakemake jobs do to a resident-index server (Snakefile:431-487): requests arrive together.
-    A cold index (fed through a FIFO that stalls for 2 s) is loaded by its own handler thread; meanwhile three
+    A cold index (fed through a FIFO that stalls for 4 s) is loaded by its own handler thread; meanwhile three
     clients with the same query file against three resident batches are answered at once -- by ONE fused search --,
     a second client of the cold index waits for the same load instead of starting another, and every answer is
     byte-identical to the oracle."""
@@ -401,7 +401,7 @@ def test_server_keeps_serving_during_a_cold_load_and_fuses_concurrent_jobs(pm, o
             with open(cold_path, "wb") as f:
                 f.write(cold_bytes[: len(cold_bytes) // 2])
                 f.flush()
-                time.sleep(2.0)
+                time.sleep(4.0)
                 f.write(cold_bytes[len(cold_bytes) // 2:])
         out, lat = {}, {}
 
@@ -422,11 +422,11 @@ def test_server_keeps_serving_during_a_cold_load_and_fuses_concurrent_jobs(pm, o
         for b in range(3):
             head, body = out[f"res{b}"]
             assert head["ok"] and head["cached"] and body == cases[b][2], b
-            assert lat[f"res{b}"] < 1.5, lat               # answered while the cold index was still loading
+            assert lat[f"res{b}"] < 3.0, lat               # answered while the cold index was still loading
         for name in ("cold_a", "cold_b"):
             head, body = out[name]
             assert head["ok"] and body == cold_text
-            assert lat[name] > 1.5
+            assert lat[name] > 3.0
         st, _ = request(sock, {"op": "stats"})
         assert st["loads"] == 4 and st["waited_for_a_load"] >= 1 and st["resident"] == 4
         assert st["max_batches_in_one_search"] >= 3 and st["searches"] < st["jobs"] == 5

@@ -265,6 +265,12 @@ int  pm_format_hits_limit(const pm_index_t* idx, const pm_queries_t* q,
 int  pm_format_hits_gz(const pm_index_t* idx, const pm_queries_t* q,
                        const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits,
                        const char* path, int level, uint64_t* text_bytes, uint64_t* gz_bytes);
+/* the same when the query set is searched in chunks (more reads than fit HBM at once): the pieces of a batch's file are
+ * written in query order into "<path>.tmp" -- piece 1 = first (creates it), 2 = middle (appends), 3 = last (appends and
+ * renames to `path`), 0 = the whole file; gzip members simply follow each other. */
+int  pm_format_hits_gz_piece(const pm_index_t* idx, const pm_queries_t* q,
+                             const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits,
+                             const char* path, int level, int piece, uint64_t* text_bytes, uint64_t* gz_bytes);
 /* one-shot: what `cobs query -i INDEX -f FASTA -t T` prints */
 int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
                    double threshold, int64_t nb_best_hits, char** text, size_t* len);

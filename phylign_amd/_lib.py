@@ -98,6 +98,8 @@ SYMBOLS = [
     ("pm_format_hits_limit", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_format_hits_gz", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.c_char_p, C.c_int,
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("pm_format_hits_gz_piece", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.c_char_p, C.c_int, C.c_int,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pm_merge_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     ("pm_merge_add", C.c_int, [_P, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
     ("pm_merge_add_text", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_size_t]),
@@ -473,12 +475,13 @@ def format_hits(index: Index, queries: Queries, hits, slot=0, nb_best_hits=-1) -
     return out
 
 
-def format_hits_gz(index: Index, queries: Queries, hits, path, slot=0, nb_best_hits=-1, level=1):
-    """writes the batch's 03_match file (text of format_hits, gzip members, atomic rename); returns (text bytes, gz bytes)"""
+def format_hits_gz(index: Index, queries: Queries, hits, path, slot=0, nb_best_hits=-1, level=1, piece=0):
+    """writes the batch's 03_match file (text of format_hits, gzip members, atomic rename); returns (text bytes, gz bytes).
+    piece: 0 = the whole file; for a query set searched in chunks 1 = first piece, 2 = middle, 3 = last (see the header)"""
     hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
     t, z = C.c_uint64(), C.c_uint64()
-    _chk(load().pm_format_hits_gz(index._h, queries._h, hits.ctypes.data, hits.size, slot, nb_best_hits,
-                                  os.fsencode(path), level, C.byref(t), C.byref(z)))
+    _chk(load().pm_format_hits_gz_piece(index._h, queries._h, hits.ctypes.data, hits.size, slot, nb_best_hits,
+                                        os.fsencode(path), level, piece, C.byref(t), C.byref(z)))
     return t.value, z.value
 
 

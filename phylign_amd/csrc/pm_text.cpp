@@ -175,9 +175,26 @@ static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit
 // line boundaries into chunks of ~4 MiB that are deflated in parallel as consecutive gzip MEMBERS (a multi-member file is
 // a valid gzip stream: `gzip -dc`, xopen and Python's gzip decode it to the same bytes -- scripts/filter_queries.py:46
 // reads through xopen), and written to "<path>.tmp" + rename.  Nothing of it passes through the caller.
+static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
+                               uint32_t slot, int64_t nb_best, const char* path, int level, int piece,
+                               uint64_t* text_bytes, uint64_t* gz_bytes);
 extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
                                  uint32_t slot, int64_t nb_best, const char* path, int level,
                                  uint64_t* text_bytes, uint64_t* gz_bytes) {
+    return format_hits_gz_impl(ix, q, hits, n_hits, slot, nb_best, path, level, 0, text_bytes, gz_bytes);
+}
+// The same for a query set that is searched in CHUNKS (a file of more reads than fit HBM at once): the pieces of a batch's
+// file are written one after the other -- gzip members may simply follow each other -- into "<path>.tmp":
+// piece 1 = first (creates it), 2 = a middle one (appends), 3 = the last (appends, then renames to `path`); 0 = the whole file.
+extern "C" int pm_format_hits_gz_piece(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
+                                       uint32_t slot, int64_t nb_best, const char* path, int level, int piece,
+                                       uint64_t* text_bytes, uint64_t* gz_bytes) {
+    if (piece < 0 || piece > 3) return fail(PM_EINVAL, "piece must be 0 (whole), 1 (first), 2 (middle) or 3 (last)");
+    return format_hits_gz_impl(ix, q, hits, n_hits, slot, nb_best, path, level, piece, text_bytes, gz_bytes);
+}
+static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
+                               uint32_t slot, int64_t nb_best, const char* path, int level, int piece,
+                               uint64_t* text_bytes, uint64_t* gz_bytes) {
     if (!path || level < 0 || level > 9) return fail(PM_EINVAL, "bad argument");
     std::vector<std::string> parts;
     { int rc = format_parts(ix, q, hits, n_hits, slot, nb_best, 0, parts); if (rc) return rc; }
@@ -220,8 +237,9 @@ extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, co
     parallel_for(chunks.size(), deflate_one);
     for (int rc : zrc) if (rc != Z_OK) return fail(PM_EIO, "zlib deflate failed (%d)", rc);
     const std::string tmp = std::string(path) + ".tmp";
-    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) return fail(PM_EIO, "cannot create '%s': %s", tmp.c_str(), strerror(errno));
+    const bool append = piece == 2 || piece == 3, finish = piece == 0 || piece == 3;
+    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | (append ? O_APPEND : O_TRUNC), 0644);
+    if (fd < 0) return fail(PM_EIO, "cannot %s '%s': %s", append ? "append to" : "create", tmp.c_str(), strerror(errno));
     uint64_t gz = 0;
     int e = 0;
     for (const std::string& m2 : members) {
@@ -235,7 +253,7 @@ extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, co
     }
     if (close(fd) != 0 && !e) e = errno;
     if (e) { (void)unlink(tmp.c_str()); return fail(PM_EIO, "writing '%s': %s", tmp.c_str(), strerror(e)); }
-    if (rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
+    if (finish && rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
     if (text_bytes) *text_bytes = total;
     if (gz_bytes) *gz_bytes = gz;
     return PM_OK;

@@ -159,23 +159,47 @@ class ResidentSource:
         return self.indexes[batch]
 
 
+def split_prepared_fasta(fasta, max_records):
+    """cuts a prepared query file (records start with '>' or ';' at a line start) into pieces of at most max_records
+    records; returns the list of byte strings (one piece when max_records <= 0)"""
+    if max_records <= 0:
+        return [fasta]
+    arr = np.frombuffer(fasta, dtype=np.uint8)
+    nl = np.flatnonzero(arr[:-1] == 10)
+    nxt = arr[nl + 1]
+    starts = nl[(nxt == 62) | (nxt == 59)] + 1                    # '>' or ';' right after a newline
+    if len(arr) and arr[0] in (62, 59):
+        starts = np.concatenate(([0], starts))
+    if len(starts) <= max_records:
+        return [fasta]
+    cuts = [int(starts[i]) for i in range(max_records, len(starts), max_records)]
+    bounds = [0] + cuts + [len(fasta)]
+    return [fasta[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)]
+
+
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
               want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
-    `batches`).  Returns (report dict, pm.Merge or None).  keep_texts: optional dict that receives
-    {batch: post-filtered text} (tests)."""
+    `batches`).  `queries` is one pm.Queries or a LIST of them: the chunks, in file order, of a query file with more reads
+    than fit HBM at once -- every group of resident batches is then searched chunk after chunk (the pipeline's units are
+    (group, chunk) pairs), a batch's file grows by one piece per chunk, and there is one merge per chunk.  Returns
+    (report dict, pm.Merge / list of pm.Merge / None).  keep_texts: optional dict that receives {batch: post-filtered text}
+    (tests)."""
     from . import pgzip
     t_start = time.perf_counter()
     os.makedirs(out_dir, exist_ok=True)
-    nq, n_terms = queries.count()
+    chunks = list(queries) if isinstance(queries, (list, tuple)) else [queries]
+    nc = len(chunks)
+    nq = sum(c.count()[0] for c in chunks)
+    n_terms = sum(c.count()[1] for c in chunks)
     nb = nb_best_hits
     budget = budget_bytes if budget_bytes else 0.6 * pm.device_info()["hbm_free"]
     admit = Admission(budget)
-    merge = pm.Merge(queries, keep=nb) if want_merge else None
+    merges = [pm.Merge(c, keep=nb) for c in chunks] if want_merge else None
     ready, ready_cv, failed = [], threading.Condition(), []
     acc = {"load_s": 0.0, "format_s": 0.0, "gzip_s": 0.0, "merge_s": 0.0, "match_only_s": 0.0, "gpu_wait_s": 0.0,
            "d2h_s": 0.0}
-    acc_mu, merge_mu, merge_order = threading.Lock(), threading.Lock(), []
+    acc_mu, merge_mu, merge_orders = threading.Lock(), threading.Lock(), [[] for _ in chunks]
 
     def add_time(key, dt):
         with acc_mu:
@@ -221,8 +245,10 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     workers = ThreadPoolExecutor(max_workers=max(2, min(6, len(os.sched_getaffinity(0)) // 2)))
     group_rows = []
 
-    def finish(group, res, t_queued):
-        """host half of a group: runs while the GPU scans the next one"""
+    def finish(group, ci, res, t_queued):
+        """host half of a (group, chunk) unit: runs while the GPU scans the next one"""
+        qc = chunks[ci]
+        piece = 0 if nc == 1 else (1 if ci == 0 else (3 if ci == nc - 1 else 2))
         t0 = time.perf_counter()
         res.wait()
         st = res.stats
@@ -236,62 +262,71 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             pos, ix, _held = group[i]
             b = batches[pos]
             part = hits[cut[i]:cut[i + 1]]
+            path = os.path.join(out_dir, f"{b}____{qfile}.gz")
             ta = time.perf_counter()
             if keep_texts is None:
                 # records -> post-filtered text -> `gzip --fast` members -> file, all inside the library (Snakefile:463-469)
-                pm.format_hits_gz(ix, queries, part, os.path.join(out_dir, f"{b}____{qfile}.gz"), slot=i, nb_best_hits=nb, level=1)
+                pm.format_hits_gz(ix, qc, part, path, slot=i, nb_best_hits=nb, level=1, piece=piece)
                 text = None
                 tb = tc = tc0 = time.perf_counter()
             else:
-                text = pm.format_hits(ix, queries, part, slot=i, nb_best_hits=nb)
+                text = pm.format_hits(ix, qc, part, slot=i, nb_best_hits=nb)
                 tb = time.perf_counter()
-                # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
-                pgzip.write(os.path.join(out_dir, f"{b}____{qfile}.gz"), text, level=1, pool=deflaters)
+                keep_texts[b] = keep_texts.get(b, b"") + text if ci else text
+                if ci == nc - 1:
+                    # `gzip --fast` (Snakefile:468), deflated in parallel as consecutive gzip members
+                    pgzip.write(path, keep_texts[b], level=1, pool=deflaters)
                 tc = tc0 = time.perf_counter()
             td = tc
-            if merge is not None:
+            if merges is not None:
                 with merge_mu:                           # the library serialises adds anyway; the ordinal of the add is the export's slot
                     tc = time.perf_counter()             # (time spent waiting for the lock is not merge work)
-                    merge.add(b, ix, part, slot=i, nb_best_hits=nb)
-                    merge_order.append(b)
+                    merges[ci].add(b, ix, part, slot=i, nb_best_hits=nb)
+                    merge_orders[ci].append(b)
                     td = time.perf_counter()
-            add_time("format_s", tb - ta); add_time("gzip_s", (tc if merge is None else tc0) - tb); add_time("merge_s", td - tc)
-            if keep_texts is not None:
-                keep_texts[b] = text
+            add_time("format_s", tb - ta); add_time("gzip_s", (tc if merges is None else tc0) - tb); add_time("merge_s", td - tc)
             return len(part)
         n_rec = list(workers.map(one, range(len(group))))
         res.free()
-        for pos, ix, held in group:
-            if not resident:
-                ix.free()
-            admit.release(held)
-        group_rows.append({"batches": [batches[p] for p, _, _ in group], "scan_launches": int(st.n_scan_launches),
-                           "gpu_ms": round(st.ms_total, 3), "records": int(sum(n_rec)),
-                           "queued_to_done_s": round(time.perf_counter() - t_queued, 3)})
+        if ci == nc - 1:                                 # the group has seen every chunk: its matrices may go
+            for pos, ix, held in group:
+                if not resident:
+                    ix.free()
+                admit.release(held)
+        row = {"batches": [batches[p] for p, _, _ in group], "scan_launches": int(st.n_scan_launches),
+               "gpu_ms": round(st.ms_total, 3), "records": int(sum(n_rec)),
+               "queued_to_done_s": round(time.perf_counter() - t_queued, 3)}
+        if nc > 1:
+            row["chunk"] = ci
+        group_rows.append(row)
 
     resident = bool(getattr(source, "resident", False))
     if resident:                                        # nothing to decode: every batch is ready, no loader threads
         ready.extend((pos, source.load(batches[pos]), 0.0) for pos in mine)
-        if max_group <= 0 and len(mine) >= 16:
+        if max_group <= 0 and len(mine) >= 16 and nc == 1:
             # two halves instead of one group: the host half of the first (text, gzip, merge) overlaps the scan of the second
             max_group = (len(mine) + 1) // 2
     with ThreadPoolExecutor(max_workers=max(1, loaders)) as pool:
         futures = [] if resident else [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
         try:
-            left, pending = len(mine), None
-            while left or pending:
-                group = take_ready(block=pending is None) if left else []
+            left, pending, backlog = len(mine), None, []
+            while left or backlog or pending:
+                if not backlog and left:
+                    group = take_ready(block=pending is None)
+                    if group:
+                        for pos, ix, _ in group:
+                            info = ix.info
+                            if ix.device != pm.bound_device():
+                                raise SystemExit(f"batch {batches[pos]}: matrix is on GPU {ix.device}, this rank drives GPU {pm.bound_device()}")
+                            if info.term_size != kmer_size:
+                                raise SystemExit(f"batch {batches[pos]}: term_size {info.term_size} != {kmer_size} (--kmer-size)")
+                        backlog = [(group, ci) for ci in range(nc)]
+                        left -= len(group)
                 cur = None
-                if group:
-                    for pos, ix, _ in group:
-                        info = ix.info
-                        if ix.device != pm.bound_device():
-                            raise SystemExit(f"batch {batches[pos]}: matrix is on GPU {ix.device}, this rank drives GPU {pm.bound_device()}")
-                        if info.term_size != kmer_size:
-                            raise SystemExit(f"batch {batches[pos]}: term_size {info.term_size} != {kmer_size} (--kmer-size)")
+                if backlog:
+                    group, ci = backlog.pop(0)
                     tq = time.perf_counter()
-                    cur = (group, pm.search_async([ix for _, ix, _ in group], queries, threshold, nb_best_hits=max(nb, 0)), tq)
-                    left -= len(group)
+                    cur = (group, ci, pm.search_async([ix for _, ix, _ in group], chunks[ci], threshold, nb_best_hits=max(nb, 0)), tq)
                 if pending:
                     finish(*pending)
                 pending = cur
@@ -302,15 +337,17 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             raise
     workers.shutdown()
     deflaters.shutdown()
-    report = {"batches": len(mine), "queries": nq, "kmers": n_terms, "groups": len(group_rows),
+    report = {"batches": len(mine), "queries": nq, "kmers": n_terms, "query_chunks": nc, "groups": len(group_rows),
               "scan_launches": sum(g["scan_launches"] for g in group_rows),
               "match_only_s": round(acc["match_only_s"], 4), "gpu_wait_s": round(acc["gpu_wait_s"], 4),
               "d2h_s": round(acc["d2h_s"], 4), "load_s_thread_sum": round(acc["load_s"], 3),
               "format_s_thread_sum": round(acc["format_s"], 3), "gzip_s_thread_sum": round(acc["gzip_s"], 3),
               "format_and_gzip_in_library": keep_texts is None,
               "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
-              "per_group": group_rows, "merge_order": merge_order}
-    return report, merge
+              "per_group": group_rows, "merge_order": merge_orders[0] if nc == 1 else merge_orders}
+    if merges is None:
+        return report, None
+    return report, (merges if isinstance(queries, (list, tuple)) else merges[0])
 
 
 def bind_rank_to_gpu(local_rank, n_visible):
@@ -338,6 +375,9 @@ def main(argv=None):
                     help="concurrent xz decoders per rank (0 = the CPUs the job may use minus 4, at least 4, at most 16: one "
                          "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for)")
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
+    ap.add_argument("--query-chunk", type=int, default=4_000_000,
+                    help="most reads searched at once (0 = the whole file): a query set lives in HBM with 8 bytes per k-mer, so a "
+                         "file of tens of millions of reads is searched chunk after chunk against the resident batches")
     ap.add_argument("--kmer-size", type=int, default=31, help="k of the indexes (31 for the 661k collection); every batch's header is checked against it")
     ap.add_argument("--max-group", type=int, default=0, help="most batches fused into one search (0 = every resident batch)")
     ap.add_argument("--raw-queries", action="store_true",
@@ -388,43 +428,71 @@ def main(argv=None):
     qfile = qfile[:-3] if qfile.endswith(".fa") else qfile
     with open(args.queries, "rb") as f:
         fasta = f.read()
-    queries = pm.Queries(fasta, term_size=args.kmer_size, normalise=args.raw_queries)   # checked against every batch's header
+    # a query file with more reads than --query-chunk is searched in pieces: the chunks share the resident batches of a
+    # group, every batch's file grows by one piece per chunk, and the 04_filter FASTA is emitted chunk after chunk
+    if args.raw_queries:
+        prepared = pm.Queries(fasta, term_size=args.kmer_size, normalise=True)
+        if prepared.count()[0] > args.query_chunk > 0:
+            fasta = prepared.fasta()                               # the prepared single-line form can be cut at '>' lines
+            prepared.free()
+            prepared = None
+    else:
+        prepared = None
+    pieces = [fasta] if prepared is not None else split_prepared_fasta(fasta, args.query_chunk)
+    if prepared is not None:
+        chunk_list = [prepared]
+    else:
+        chunk_list = [pm.Queries(p_, term_size=args.kmer_size) for p_ in pieces]   # checked against every batch's header
+    del pieces, fasta
     budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else None
     if args.loaders <= 0:
         from .sysinfo import effective_cpus
         args.loaders = max(4, min(16, effective_cpus() - 4))
-    report, merge = run_stage(pm, batches, mine, source, queries, qfile, args.out_dir, args.threshold, args.nb_best_hits,
-                              want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
-                              max_group=args.max_group, kmer_size=args.kmer_size)
+    report, merges = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
+                               want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
+                               max_group=args.max_group, kmer_size=args.kmer_size)
+    orders = report["merge_order"] if len(chunk_list) > 1 else [report["merge_order"]]
 
-    # ---- 04_filter: one gather of what every rank's merge kept, rank 0 adds the parts and emits
+    # ---- 04_filter: per chunk one gather of what every rank's merge kept, rank 0 adds the parts and emits
     t_f = time.perf_counter()
     if args.filter_out:
         if world > 1:
-            ex = merge.export()                                      # slot = ordinal of the add = position in merge_order
-            t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
-            if backend == "nccl":
-                t = t.cuda()
-            g = gather_hits(t, dst=0)
-            meta = [None] * world if rank == 0 else None
-            dist.gather_object((len(ex), report["merge_order"]), meta, dst=0)
-            if rank == 0:
-                allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
-                off = 0
-                for r, (n, r_order) in enumerate(meta):
-                    part = allrec[off:off + n]
-                    off += n
-                    if r == 0:
-                        continue                                      # rank 0's own matches are in `merge` already
-                    cut = np.searchsorted(part["slot"], np.arange(len(r_order) + 1, dtype=np.uint32))
-                    for k, b in enumerate(r_order):
-                        if cut[k + 1] > cut[k]:
-                            nix = names_index(pm, source, b)
-                            merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1)
-                            nix.free()
+            for ci, merge in enumerate(merges):
+                ex = merge.export()                                  # slot = ordinal of the add = position in the chunk's merge order
+                t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
+                if backend == "nccl":
+                    t = t.cuda()
+                g = gather_hits(t, dst=0)
+                meta = [None] * world if rank == 0 else None
+                dist.gather_object((len(ex), orders[ci]), meta, dst=0)
+                if rank == 0:
+                    allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+                    off = 0
+                    for r, (n, r_order) in enumerate(meta):
+                        part = allrec[off:off + n]
+                        off += n
+                        if r == 0:
+                            continue                                  # rank 0's own matches are in `merge` already
+                        cut = np.searchsorted(part["slot"], np.arange(len(r_order) + 1, dtype=np.uint32))
+                        for k, b in enumerate(r_order):
+                            if cut[k + 1] > cut[k]:
+                                nix = names_index(pm, source, b)
+                                merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1)
+                                nix.free()
         if rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
-            report["filter_fasta_bytes"] = merge.emit_to(args.filter_out)
+            if len(merges) == 1:
+                report["filter_fasta_bytes"] = merges[0].emit_to(args.filter_out)
+            else:
+                tmp = args.filter_out + ".tmp"
+                total = 0
+                with open(tmp, "wb") as f:
+                    for merge in merges:                              # chunks are in file order: so are the records
+                        piece = merge.emit()
+                        f.write(piece)
+                        total += len(piece)
+                os.replace(tmp, args.filter_out)
+                report["filter_fasta_bytes"] = total
     report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
     if world > 1:
         dist.barrier()

@@ -222,6 +222,31 @@ def test_match_stage_searches_resident_batches_with_fused_launches(pm, oracle, t
     json.dumps(report2)
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_match_stage_searches_a_large_query_file_in_chunks(pm, oracle, tmp_path, ranks):
+    """--query-chunk: 20 reads in chunks of 7 (3 chunks) against batches that stream through a tiny HBM budget -- every
+    batch's file is written piece by piece, the 04_filter FASTA chunk by chunk, and both equal the one-piece run's
+    (one rank, and two ranks with the per-chunk gather over gloo)"""
+    import json
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable]
+    if ranks == 2:
+        env.update(PHYLIGN_DIST_BACKEND="gloo", PHYLIGN_SHARE_GPU="1")
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29543"]
+    cmd += ["-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"), "--cobs-dir", str(tmp_path / "cobs"),
+            "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"), "--out-dir", str(tmp_path / "03_match"),
+            "--nb-best-hits", "3", "--filter-out", str(tmp_path / "04_filter" / "Q.fa"), "--loaders", "2",
+            "--query-chunk", "7", "--max-resident-gb", "0.0000001"]
+    r = subprocess.run(cmd, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    reports = [json.loads(l) for l in r.stderr.decode().splitlines() if l.startswith("{") and '"query_chunks"' in l]
+    assert reports and all(rep["query_chunks"] == 3 for rep in reports)
+    assert sum(rep["groups"] for rep in reports) >= 3 * 1 and not list((tmp_path / "03_match").glob("*.tmp"))
+
+
 def test_match_stage_takes_unprepared_queries(pm, oracle, tmp_path):
     """--raw-queries: rule fix_query (Snakefile:314-333) runs inside the native parser; same outputs as
     for the prepared file"""

@@ -36,6 +36,7 @@ def main():
                          "whose home is in this shard find hundreds of documents around the threshold there")
     ap.add_argument("--max-group", type=int, nargs="*", default=[0], help="0 = all resident batches in one search; several values = several runs")
     ap.add_argument("--bound", type=int, default=1)
+    ap.add_argument("--query-chunk", type=int, default=0, help="search the query file in chunks of this many reads (0 = at once)")
     ap.add_argument("--out", default="gpurun_out/e2e")
     args = ap.parse_args()
 
@@ -48,12 +49,16 @@ def main():
     fasta, _ = W.make_queries(args.queries, args.qlen, seed=5)
     t_make = time.perf_counter() - t0
     t0 = time.perf_counter()
-    q = pm.Queries(fasta)
+    pieces = MS.split_prepared_fasta(fasta, args.query_chunk)
+    qs = [pm.Queries(p) for p in pieces]
     t_parse = time.perf_counter() - t0
-    nq, n_terms = q.count()
+    q = qs[0]
+    nq, n_terms = sum(x.count()[0] for x in qs), sum(x.count()[1] for x in qs)
+    del pieces
     t0 = time.perf_counter()
+    nq0 = q.count()[0]                                   # planted reads come from the first chunk
     hashes = q.hash_terms(1, 1)
-    plan, sure = W.plant_plan(hashes, nq, args.qlen - 30, sub, every=max(1, nq // 400), docs_per_query=12)
+    plan, sure = W.plant_plan(hashes, nq0, args.qlen - 30, sub, every=max(1, nq0 // 400), docs_per_query=12)
     del hashes
     ixs = {}
     for i, s in enumerate(sub):
@@ -61,7 +66,8 @@ def main():
         if i in plan:
             ix.plant(*plan[i])
         if args.clustered:
-            ix.plant_cluster(q, mine[i], len(shapes), seed=97)
+            for x in qs:
+                ix.plant_cluster(x, mine[i], len(shapes), seed=97)
         ixs[s.batch] = ix
     t_gen = time.perf_counter() - t0
     names = sorted(ixs)
@@ -75,13 +81,22 @@ def main():
         shutil.rmtree(out_dir, ignore_errors=True)
         for warm in (True, False):               # first pass warms the pooled hit / pinned buffers (as a long-running stage has them)
             t0 = time.perf_counter()
-            report, merge = MS.run_stage(pm, names, list(range(len(names))), src, q, "Q", out_dir, args.threshold,
-                                         args.nb_best_hits, want_merge=True, max_group=mg)
+            report, merges = MS.run_stage(pm, names, list(range(len(names))), src, qs, "Q", out_dir, args.threshold,
+                                          args.nb_best_hits, want_merge=True, max_group=mg)
             t1 = time.perf_counter()
             os.makedirs(os.path.join(args.out, "04_filter"), exist_ok=True)
-            fasta_bytes = merge.emit_to(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
+            if len(merges) == 1:
+                fasta_bytes = merges[0].emit_to(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
+            else:
+                fasta_bytes = 0
+                with open(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"), "wb") as f:
+                    for m_ in merges:
+                        piece = m_.emit()
+                        f.write(piece)
+                        fasta_bytes += len(piece)
             t2 = time.perf_counter()
-            merge.free()
+            for m_ in merges:
+                m_.free()
             if warm and args.queries > 200_000:
                 break                            # one pass is enough at 1 M queries (the pools matter little there)
         gz = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
@@ -90,7 +105,7 @@ def main():
                       f"{alg_per_kmer} row bytes per k-mer; {nq} x {args.qlen} bp queries, threshold {args.threshold}, "
                       f"nb_best_hits {args.nb_best_hits}, {'clustered home batches' if args.clustered else 'i.i.d. + planted'}, "
                       f"threshold bound {'on' if args.bound else 'off'}",
-            "max_group": mg, "groups": report["groups"], "scan_launches": report["scan_launches"],
+            "max_group": mg, "query_chunks": report["query_chunks"], "groups": report["groups"], "scan_launches": report["scan_launches"],
             "parse_queries_s": round(t_parse, 3),
             "match_only_s": report["match_only_s"],
             "match_only_kmers_per_s": n_terms / report["match_only_s"],

@@ -948,3 +948,40 @@ def test_worker_pool_serves_concurrent_callers(tmp_path):
     for x in th:
         x.join()
     assert not errors, errors[:2]
+
+
+def test_match_file_pieces_and_query_file_splitting(tmp_path):
+    """a query file cut into chunks (match_stage --query-chunk): the pieces of a batch's file, written chunk after chunk
+    (pm_format_hits_gz_piece), gunzip to the one-piece text; the splitter cuts only at record starts"""
+    import gzip
+    from phylign_amd import _lib as pm
+    from phylign_amd.match_stage import split_prepared_fasta
+    n = 1000
+    recs = [(b";semi%d\n" % i if i % 97 == 0 else b">q%04d c\n" % i) + b"ACGTACGTACGTACGTACGTACGTACGTACGTACG\n" for i in range(n)]
+    fasta = b"".join(recs)
+    for size in (0, 1, 250, 333, 999, 1000, 5000):
+        pieces = split_prepared_fasta(fasta, size)
+        assert b"".join(pieces) == fasta
+        assert all(p[:1] in (b">", b";") for p in pieces)
+        assert len(pieces) == (1 if size <= 0 or size >= n else -(-n // size))
+    ix = pm.Index.from_names([f"{i:05x}_R{i}" for i in range(40)])
+    rng = np.random.default_rng(4)
+    whole_q = pm.Queries(fasta, term_size=31)
+    recs_all = np.zeros(3 * n, dtype=pm.HIT_DTYPE)
+    recs_all["query"] = np.repeat(np.arange(n, dtype=np.uint32), 3); recs_all["doc"] = rng.integers(0, 40, 3 * n); recs_all["score"] = rng.integers(1, 6, 3 * n)
+    pm.sort_hits(recs_all)
+    want = pm.format_hits(ix, whole_q, recs_all, slot=0, nb_best_hits=2)
+    pieces = split_prepared_fasta(fasta, 333)
+    path = tmp_path / "b____q.gz"
+    first = 0
+    for ci, piece in enumerate(pieces):
+        qc = pm.Queries(piece, term_size=31)
+        k = qc.count()[0]
+        part = recs_all[(recs_all["query"] >= first) & (recs_all["query"] < first + k)].copy()
+        part["query"] -= first
+        pm.format_hits_gz(ix, qc, part, str(path), slot=0, nb_best_hits=2, piece=1 if ci == 0 else (3 if ci == len(pieces) - 1 else 2))
+        assert path.exists() == (ci == len(pieces) - 1)           # the file appears with its last piece
+        first += k
+    assert gzip.open(path, "rb").read() == want and not (tmp_path / "b____q.gz.tmp").exists()
+    with pytest.raises(pm.PMError):
+        pm.format_hits_gz(ix, whole_q, recs_all, str(path), piece=7)

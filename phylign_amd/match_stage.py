@@ -498,7 +498,8 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     report.update({"rank": rank, "world": world, "e2e_s": round(time.perf_counter() - t_start, 3)})
-    print(json.dumps(report), file=sys.stderr)
+    sys.stderr.write(json.dumps(report) + "\n")          # one write: the lines of several ranks must not interleave
+    sys.stderr.flush()
 
 
 def names_index(pm, source, batch):

@@ -242,9 +242,8 @@ def test_match_stage_searches_a_large_query_file_in_chunks(pm, oracle, tmp_path,
     r = subprocess.run(cmd, capture_output=True, env=env)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
-    reports = [json.loads(l) for l in r.stderr.decode().splitlines() if l.startswith("{") and '"query_chunks"' in l]
-    assert reports and all(rep["query_chunks"] == 3 for rep in reports)
-    assert sum(rep["groups"] for rep in reports) >= 3 * 1 and not list((tmp_path / "03_match").glob("*.tmp"))
+    assert r.stderr.count(b'"query_chunks": 3') == ranks          # every rank reports its three chunks
+    assert not list((tmp_path / "03_match").glob("*.tmp"))
 
 
 def test_match_stage_takes_unprepared_queries(pm, oracle, tmp_path):

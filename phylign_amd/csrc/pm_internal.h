@@ -81,6 +81,7 @@ hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, ui
                                 uint64_t seed, hipStream_t st);
 hipError_t launch_publish(const unsigned long long* src, unsigned long long* dst_mapped, int n, hipStream_t st);
 hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* src, uint4* dst, hipStream_t st);
+hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst, hipStream_t st);
 hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
                         uint64_t n, hipStream_t st);
 

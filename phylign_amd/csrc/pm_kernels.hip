@@ -1038,6 +1038,62 @@ hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* 
     return hipGetLastError();
 }
 
+// a7 on the device, third part: a (slot, query) group that the scan wrote as SEVERAL runs -- one per 1024-byte column slab
+// of a row wider than that, or one per sub-index of a compact index -- becomes one list in cobs' line order.  Every run
+// is ordered (score descending, ties by ascending document) and the runs cover disjoint, ordered document ranges, so a
+// record's place is a count: the records of the other runs with a higher score, those with the same score in runs of
+// lower documents, and the records ahead of it in its own run.  group = {first destination record, runs, first entry in
+// `runs`, -}; run = {first source record (behind the count record), records, -, -}.  One workgroup per group.
+__global__ __launch_bounds__(256) void k_merge_runs(const uint4* __restrict__ groups, uint32_t n_groups,
+                                                     const uint4* __restrict__ runs, const uint4* __restrict__ src,
+                                                     uint4* __restrict__ dst)
+{
+    constexpr uint32_t kStage = 512;
+    __shared__ uint32_t s_begin[kStage], s_len[kStage], s_doc[kStage];
+    for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
+        const uint4 g = groups[gi];
+        const uint32_t nr = g.y, staged = nr < kStage ? nr : kStage;
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < staged; r += blockDim.x) {
+            const uint4 rn = runs[g.z + r];
+            s_begin[r] = rn.x; s_len[r] = rn.y; s_doc[r] = src[rn.x].y;
+        }
+        __syncthreads();
+        auto run_of = [&](uint32_t r, uint32_t* b, uint32_t* l, uint32_t* d) {
+            if (r < staged) { *b = s_begin[r]; *l = s_len[r]; *d = s_doc[r]; }
+            else { const uint4 rn = runs[g.z + r]; *b = rn.x; *l = rn.y; *d = src[rn.x].y; }
+        };
+        for (uint32_t r = 0; r < nr; ++r) {
+            uint32_t b, l, d0;
+            run_of(r, &b, &l, &d0);
+            for (uint32_t i = threadIdx.x; i < l; i += blockDim.x) {
+                const uint4 rec = src[(uint64_t)b + i];
+                const uint32_t sc = rec.z;
+                uint32_t pos = i;
+                for (uint32_t o = 0; o < nr; ++o) {
+                    if (o == r) continue;
+                    uint32_t ob, ol, od;
+                    run_of(o, &ob, &ol, &od);
+                    uint32_t lo = 0, hi = ol;                      // records of run o with score > sc (scores descend)
+                    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (src[(uint64_t)ob + m].z > sc) lo = m + 1; else hi = m; }
+                    pos += lo;
+                    if (od < d0) {                                 // lower documents: their equal scores come first
+                        uint32_t lo2 = lo, hi2 = ol;
+                        while (lo2 < hi2) { const uint32_t m = (lo2 + hi2) >> 1; if (src[(uint64_t)ob + m].z >= sc) lo2 = m + 1; else hi2 = m; }
+                        pos += lo2 - lo;
+                    }
+                }
+                dst[(uint64_t)g.x + pos] = rec;
+            }
+        }
+    }
+}
+hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst, hipStream_t st) {
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_runs, dim3(n_groups < 65536u ? n_groups : 65536u), dim3(256), 0, st, groups, n_groups, runs, src, dst);
+    return hipGetLastError();
+}
+
 __global__ void k_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -130,7 +130,6 @@ struct pm_result {
     std::atomic<bool> ordered{false};              // double-checked under g_order_mu
     HitBuf d_ord{nullptr, 0};
     uint64_t n_out = 0;
-    std::vector<std::pair<uint64_t, uint64_t>> fixups;   // [begin, end) of (slot, query) groups merged from several runs
     // host copy (pinned, pooled)
     PinBuf host{nullptr, 0};
     bool host_ready = false;
@@ -662,7 +661,6 @@ static int ensure_ordered(pm_result* r) {
     std::lock_guard<std::mutex> lk(g_order_mu);
     if (r->ordered) return PM_OK;
     r->n_out = 0;
-    r->fixups.clear();
     if (r->n_records == 0) { r->ordered = true; return PM_OK; }
     hipStream_t st = g_ctx.d2h_stream;        // never behind the kernels of a later search
     const uint64_t n_runs = r->n_runs;
@@ -682,6 +680,7 @@ static int ensure_ordered(pm_result* r) {
     sort_directory(dir);
     uint64_t o = 0;
     size_t np = 0, k = 0;
+    std::vector<uint4> m_groups, m_runs;
     while (k < dir.size()) {
         size_t e = k + 1;
         while (e < dir.size() && dir[e].slot == dir[k].slot && dir[e].query == dir[k].query) ++e;
@@ -693,13 +692,14 @@ static int ensure_ordered(pm_result* r) {
             h_plan[np++] = make_uint4(d.begin + (cut ? 0u : 1u), (uint32_t)o, n, 0u);
             o += n;
         } else {
-            const uint64_t first = o;                        // several runs of one (slot, query)
+            // several runs of one (slot, query): merged into one ordered list by k_merge_runs (count records dropped:
+            // such groups are never cut on the GPU)
+            m_groups.push_back(make_uint4((uint32_t)o, (uint32_t)(e - k), (uint32_t)m_runs.size(), 0u));
             for (size_t j = k; j < e; ++j) {
                 const uint32_t len = dir[j].len & 0x7FFFFFFFu;
-                h_plan[np++] = make_uint4(dir[j].begin + 1u, (uint32_t)o, len, 0u);
+                m_runs.push_back(make_uint4(dir[j].begin + 1u, len, 0u, 0u));
                 o += len;
             }
-            r->fixups.push_back({first, o});
         }
         k = e;
     }
@@ -711,23 +711,16 @@ static int ensure_ordered(pm_result* r) {
     OCHK(hipMemcpyAsync(d_plan, h_plan, np * sizeof(uint4), hipMemcpyHostToDevice, st));
     OCHK(launch_permute_runs(d_plan, (uint32_t)np, r->d_hits, r->d_ord.p, st));
     OCHK(hipStreamSynchronize(st));
-    // groups merged from several runs (rows wider than 1024 bytes, compact sub-indexes): the span that holds them
-    // travels to the host ONCE (pinned), every group is interleaved by score there, and the span goes back once --
-    // not a pair of blocking copies per group
-    if (!r->fixups.empty()) {
-        const uint64_t lo = r->fixups.front().first, hi = r->fixups.back().second;
-        PinBuf span{nullptr, 0};
-        { int rc = take_pinned((size_t)(hi - lo) * sizeof(pm_hit_t), &span); if (rc) return done(rc); }
-        pm_hit_t* hp = (pm_hit_t*)span.p;
-        hipError_t e = hipMemcpyAsync(hp, r->d_ord.p + lo, (size_t)(hi - lo) * sizeof(pm_hit_t), hipMemcpyDeviceToHost, st);
+    // groups written as several runs (rows wider than 1024 bytes, compact sub-indexes) are merged on the device
+    if (!m_groups.empty()) {
+        HitBuf mp{nullptr, 0};
+        { int rc = take_hit_buffer(m_groups.size() + m_runs.size(), &mp); if (rc) return done(rc); }
+        hipError_t e = hipMemcpyAsync(mp.p, m_groups.data(), m_groups.size() * sizeof(uint4), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(mp.p + m_groups.size(), m_runs.data(), m_runs.size() * sizeof(uint4), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = launch_merge_runs(mp.p, (uint32_t)m_groups.size(), mp.p + m_groups.size(), r->d_hits, r->d_ord.p, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e == hipSuccess) {
-            for (auto& f : r->fixups) std::sort(hp + (f.first - lo), hp + (f.second - lo), hit_less);
-            e = hipMemcpyAsync(r->d_ord.p + lo, hp, (size_t)(hi - lo) * sizeof(pm_hit_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-        }
-        give_pinned(span);
-        if (e != hipSuccess) return done(fail(PM_EHIP, "ordering of multi-run groups: %s", hipGetErrorString(e)));
+        give_hit_buffer(mp);
+        if (e != hipSuccess) return done(fail(PM_EHIP, "merging multi-run groups: %s", hipGetErrorString(e)));
     }
 #undef OCHK
     r->ordered = true;

@@ -624,7 +624,7 @@ extern "C" void pm_hits_sort(pm_hit_t* hits, uint64_t n) {
 // it into a copy plan, and k_permute_runs moves every run to its final place in HBM.  The
 // count record of a run that was not cut on the GPU carries no information (its count is
 // the run length) and is dropped.  Several runs of one (slot, query) (rows wider than 1024
-// bytes, compact sub-indexes) are laid out back to back and merged by score on the host.
+// bytes, compact sub-indexes) are merged into one ordered list by k_merge_runs.
 struct RunEnt { uint32_t query, slot, begin, len; };      // len bit 31: the list was cut to the n best
 static void sort_directory(std::vector<RunEnt>& dir) {
     auto key = [](const RunEnt& d) { return ((uint64_t)d.slot << 32) | d.query; };

@@ -528,28 +528,34 @@ def main():
     # ---- clustered variant: every query gets a home batch (changes the resident matrices: last)
     clustered = None
     if full and not args.no_clustered and (world == 1 or args.clustered_multi):
-        t0 = time.time()
-        for pos, ix in zip(mine, indexes):
-            ix.plant_cluster(q, pos, len(shapes), seed=97)
-        log(f"[bench] clustered planting {time.time() - t0:.1f}s")
-        c_runs = {}
-        for m in modes:
-            # 3 warm-up steps: the hit lists are ~700x longer here, and the pooled device / pinned
-            # buffers of two searches in flight are (re)allocated once, outside the timed steps
-            r = timed_run(m == "threshold_bound", 3, args.steps)
-            c_runs[m] = (r, fetched_pass(m == "threshold_bound"))
-        same = bool(rank != 0 or np.array_equal(c_runs[modes[0]][0]["hits"], c_runs[modes[1]][0]["hits"]))
-        ok = ok and same
-        clustered = {
-            "data": ("every query has one home batch (query i -> batch i mod %d) in which about half of the "
-                     "32-document clusters match it at a k-mer fraction of 0.60-1.0 (k_plant_cluster); elsewhere "
-                     "only the Bernoulli(1/4) background" % len(shapes)),
-            "hits_identical": same,
-        }
-        for m in modes:
-            clustered[m] = summary(c_runs[m][0], args.steps, m, c_runs[m][1])
-        clustered["threshold_bound"]["speed_vs_fetch_all_rows"] = (clustered["threshold_bound"]["value"] /
-                                                                   clustered["fetch_all_rows"]["value"])
+        try:
+            t0 = time.time()
+            for pos, ix in zip(mine, indexes):
+                ix.plant_cluster(q, pos, len(shapes), seed=97)
+            log(f"[bench] clustered planting {time.time() - t0:.1f}s")
+            c_runs = {}
+            for m in modes:
+                # 3 warm-up steps: the hit lists are ~700x longer here, and the pooled device / pinned
+                # buffers of two searches in flight are (re)allocated once, outside the timed steps
+                r = timed_run(m == "threshold_bound", 3, args.steps)
+                c_runs[m] = (r, fetched_pass(m == "threshold_bound"))
+            same = bool(rank != 0 or np.array_equal(c_runs[modes[0]][0]["hits"], c_runs[modes[1]][0]["hits"]))
+            ok = ok and same
+            clustered = {
+                "data": ("every query has one home batch (query i -> batch i mod %d) in which about half of the "
+                         "32-document clusters match it at a k-mer fraction of 0.60-1.0 (k_plant_cluster); elsewhere "
+                         "only the Bernoulli(1/4) background" % len(shapes)),
+                "hits_identical": same,
+            }
+            for m in modes:
+                clustered[m] = summary(c_runs[m][0], args.steps, m, c_runs[m][1])
+            clustered["threshold_bound"]["speed_vs_fetch_all_rows"] = (clustered["threshold_bound"]["value"] /
+                                                                       clustered["fetch_all_rows"]["value"])
+        except Exception as e:                                       # an optional leg never costs the headline line
+            if world > 1:
+                raise
+            log(f"[bench] clustered leg failed: {e!r}")
+            clustered = {"error": repr(e)}
     pm.set_option("threshold_bound", 1)
 
     # ---- BASELINE configs[3] on real GPUs: with 8 ranks (or BENCH_FULL_MIN_WORLD) ALL 305 batches of batches_full.txt are
@@ -573,44 +579,59 @@ def main():
             fbases.append(acc_b)
             acc_b += len(fparts[r])
         fplan, fsure = W.plant_plan(q.hash_terms(1, 1), nq, terms_per_q, fshapes)
-        for pos in fparts[rank]:
-            sh = fshapes[pos]
-            ix = pm.Index.synth(sh.batch_id, sh.n_docs, sh.signature_size, 1, 31, 661, layout=args.layout)
-            if pos in fplan:
-                ix.plant(*fplan[pos])
-            indexes.append(ix)
+        setup_error = None
+        try:
+            for pos in fparts[rank]:
+                sh = fshapes[pos]
+                ix = pm.Index.synth(sh.batch_id, sh.n_docs, sh.signature_size, 1, 31, 661, layout=args.layout)
+                indexes.append(ix)
+                if pos in fplan:
+                    ix.plant(*fplan[pos])
+        except Exception as e:                       # e.g. a GPU with less free memory than its shard needs
+            setup_error = repr(e)
+            log(f"[bench] full_collection: rank {rank} could not build its shard: {setup_error}")
+        # the ranks agree before the first collective of the leg: one failed shard skips it everywhere, the headline line stays
+        flag = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        fc_ready = bool(flag.item())
         finfos = [ix.info for ix in indexes]
-        log(f"[bench] full_collection: rank0 holds {len(indexes)} of {len(fshapes)} batches, "
-            f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
-        saved = dict(cur)
-        cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fshapes), "slot_base": fbases[rank],
-                    "tag": f"full/{world}", "narrow_lines_per_kmer": narrow_lines(finfos)})
-        fc_steps = max(3, min(args.steps, 10))
-        full_collection = {"workload": f"all {len(fshapes)} batches of batches_full.txt ({sum(sh.index_bytes for sh in fshapes) / 1e12:.2f} TB of "
-                                       f"signatures, {cur['rowsum']} row bytes per k-mer) sharded over {world} ranks, {nq} x {args.qlen} bp queries, "
-                                       "one gather of hit records per step",
-                           "planted_pairs_at_or_above_threshold": fsure, "rank_batches": [len(p_) for p_ in fparts]}
-        fc_runs = {}
-        for m in modes:
-            r = timed_run(m == "threshold_bound", 2, fc_steps)
-            fc_runs[m] = r
-            full_collection[m] = summary(r, fc_steps, m, None)
-            full_collection[m]["rank_ms_per_step"] = [e / fc_steps * 1e3 for e in r["rank_elapsed"]]
-        if rank == 0:
-            same = bool(np.array_equal(fc_runs[modes[0]]["hits"], fc_runs[modes[1]]["hits"]))
-            n_real = int(np.count_nonzero(fc_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
-            full_collection["hits_identical"] = same
-            ok = ok and same and n_real >= fsure
-            if args.dump_full_hits:
-                pos_of = np.zeros(len(fshapes), dtype=np.uint32)
-                for r_ in range(world):
-                    for i, pos in enumerate(fparts[r_]):
-                        pos_of[fbases[r_] + i] = pos
-                h = fc_runs[modes[0]]["hits"].copy()
-                h["slot"] = pos_of[h["slot"]]
-                np.save(args.dump_full_hits, pm.sort_hits(np.ascontiguousarray(h)))
-        cur.clear(); cur.update(saved)
-        pm.set_option("threshold_bound", 1)
+        if fc_ready:
+            log(f"[bench] full_collection: rank0 holds {len(indexes)} of {len(fshapes)} batches, "
+                f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
+            saved = dict(cur)
+            cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fshapes), "slot_base": fbases[rank],
+                        "tag": f"full/{world}", "narrow_lines_per_kmer": narrow_lines(finfos)})
+            fc_steps = max(3, min(args.steps, 10))
+            full_collection = {"workload": f"all {len(fshapes)} batches of batches_full.txt ({sum(sh.index_bytes for sh in fshapes) / 1e12:.2f} TB of "
+                                           f"signatures, {cur['rowsum']} row bytes per k-mer) sharded over {world} ranks, {nq} x {args.qlen} bp queries, "
+                                           "one gather of hit records per step",
+                               "planted_pairs_at_or_above_threshold": fsure, "rank_batches": [len(p_) for p_ in fparts]}
+            fc_runs = {}
+            for m in modes:
+                r = timed_run(m == "threshold_bound", 2, fc_steps)
+                fc_runs[m] = r
+                full_collection[m] = summary(r, fc_steps, m, None)
+                full_collection[m]["rank_ms_per_step"] = [e / fc_steps * 1e3 for e in r["rank_elapsed"]]
+            if rank == 0:
+                same = bool(np.array_equal(fc_runs[modes[0]]["hits"], fc_runs[modes[1]]["hits"]))
+                n_real = int(np.count_nonzero(fc_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
+                full_collection["hits_identical"] = same
+                ok = ok and same and n_real >= fsure
+                if args.dump_full_hits:
+                    pos_of = np.zeros(len(fshapes), dtype=np.uint32)
+                    for r_ in range(world):
+                        for i, pos in enumerate(fparts[r_]):
+                            pos_of[fbases[r_] + i] = pos
+                    h = fc_runs[modes[0]]["hits"].copy()
+                    h["slot"] = pos_of[h["slot"]]
+                    np.save(args.dump_full_hits, pm.sort_hits(np.ascontiguousarray(h)))
+            cur.clear(); cur.update(saved)
+            pm.set_option("threshold_bound", 1)
+        else:
+            full_collection = {"skipped": setup_error or "another rank could not build its shard"}
+            for ix in indexes:
+                ix.free()
+            indexes = []
 
     # ---- BASELINE configs[1] read literally: "10k synthetic 31-mer queries" = ONE k-mer per query (hit <=> bit
     # set: with Bernoulli(1/4) signatures a quarter of all documents match every query, so this leg is bound by
@@ -662,59 +683,66 @@ def main():
     # freed first: both do not fit one GPU together.
     full_shard = None
     if full and not args.no_full_shard and world == 1 and args.workload == "config3" and args.rows_divisor == 1:
-        for ix in indexes:
-            ix.free()
-        indexes = []
-        t0 = time.time()
-        fshapes = W.select("full")
-        fmine = W.assign_batches(fshapes, args.full_shard_world)[args.full_shard_rank]
-        fsub = [fshapes[p] for p in fmine]
-        fplan, fsure = W.plant_plan(q.hash_terms(1, 1), nq, terms_per_q, fsub)
-        for i, sshape in enumerate(fsub):
-            ix = pm.Index.synth(sshape.batch_id, sshape.n_docs, sshape.signature_size, 1, 31, 661, layout=args.layout)
-            if i in fplan:
-                ix.plant(*fplan[i])
-            indexes.append(ix)
-        finfos = [ix.info for ix in indexes]
-        log(f"[bench] full_shard: {len(indexes)} batches, {sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
         saved = dict(cur)
-        cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fsub), "slot_base": 0,
-                    "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_kmer": narrow_lines(finfos)})
-        fs_steps = max(3, min(args.steps, 10))
-        full_shard = {"workload": f"rank {args.full_shard_rank} of {args.full_shard_world} of batches_full.txt (305 batches, 1.06 TB, 82 741 row "
-                                  f"bytes per k-mer): {len(fsub)} batches, {sum(sh.index_bytes for sh in fsub) / 1e9:.1f} GB on disk, "
-                                  f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, {cur['rowsum']} row bytes per k-mer; "
-                                  f"{nq} x {args.qlen} bp queries",
-                      "planted_pairs_at_or_above_threshold": fsure}
-        f_runs = {}
-        for m in modes:
-            r = timed_run(m == "threshold_bound", 2, fs_steps)
-            f_runs[m] = r
-            full_shard[m] = summary(r, fs_steps, m, fetched_pass(m == "threshold_bound"))
-        same = bool(np.array_equal(f_runs[modes[0]]["hits"], f_runs[modes[1]]["hits"]))
-        n_real = int(np.count_nonzero(f_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
-        full_shard["hits_identical"] = same
-        ok = ok and same and n_real >= fsure
-        # config 5's query count: match-only rate at 1 M queries
-        t0 = time.time()
-        fasta1m, _ = W.make_queries(1_000_000, args.qlen, seed=5)
-        q1m = pm.Queries(fasta1m, term_size=31)
-        del fasta1m
-        plan1m, sure1m = W.plant_plan(q1m.hash_terms(1, 1), 1_000_000, terms_per_q, fsub, every=2500, docs_per_query=8)
-        for i, ix in enumerate(indexes):
-            if i in plan1m:
-                ix.plant(*plan1m[i])
-        cur.update({"q": q1m, "n_terms": 1_000_000 * terms_per_q, "tag": cur["tag"] + "/1M"})
-        full_shard["queries_1M"] = {"setup_s": round(time.time() - t0, 2), "planted_pairs_at_or_above_threshold": sure1m}
-        for m in modes:
-            r = timed_run(m == "threshold_bound", 1, 2)
-            sm = summary(r, 2, m, None)
-            ok = ok and sm["hits"] is not None and sm["hits"] >= sure1m
-            full_shard["queries_1M"][m] = {"value": sm["value"], "unit": "k-mers/s", "ms_per_step": sm["ms_per_step"],
-                                           "hits": sm["hits"], "roofline": sm["roofline"], "roofline_narrow": sm["roofline_narrow"]}
-        cur.clear(); cur.update(saved)
-        q1m.free()
-        pm.set_option("threshold_bound", 1)
+        try:
+            for ix in indexes:
+                ix.free()
+            indexes = []
+            t0 = time.time()
+            fshapes = W.select("full")
+            fmine = W.assign_batches(fshapes, args.full_shard_world)[args.full_shard_rank]
+            fsub = [fshapes[p] for p in fmine]
+            fplan, fsure = W.plant_plan(q.hash_terms(1, 1), nq, terms_per_q, fsub)
+            for i, sshape in enumerate(fsub):
+                ix = pm.Index.synth(sshape.batch_id, sshape.n_docs, sshape.signature_size, 1, 31, 661, layout=args.layout)
+                if i in fplan:
+                    ix.plant(*fplan[i])
+                indexes.append(ix)
+            finfos = [ix.info for ix in indexes]
+            log(f"[bench] full_shard: {len(indexes)} batches, {sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
+            saved = dict(cur)
+            cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fsub), "slot_base": 0,
+                        "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_kmer": narrow_lines(finfos)})
+            fs_steps = max(3, min(args.steps, 10))
+            full_shard = {"workload": f"rank {args.full_shard_rank} of {args.full_shard_world} of batches_full.txt (305 batches, 1.06 TB, 82 741 row "
+                                      f"bytes per k-mer): {len(fsub)} batches, {sum(sh.index_bytes for sh in fsub) / 1e9:.1f} GB on disk, "
+                                      f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, {cur['rowsum']} row bytes per k-mer; "
+                                      f"{nq} x {args.qlen} bp queries",
+                          "planted_pairs_at_or_above_threshold": fsure}
+            f_runs = {}
+            for m in modes:
+                r = timed_run(m == "threshold_bound", 2, fs_steps)
+                f_runs[m] = r
+                full_shard[m] = summary(r, fs_steps, m, fetched_pass(m == "threshold_bound"))
+            same = bool(np.array_equal(f_runs[modes[0]]["hits"], f_runs[modes[1]]["hits"]))
+            n_real = int(np.count_nonzero(f_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
+            full_shard["hits_identical"] = same
+            ok = ok and same and n_real >= fsure
+            # config 5's query count: match-only rate at 1 M queries
+            t0 = time.time()
+            fasta1m, _ = W.make_queries(1_000_000, args.qlen, seed=5)
+            q1m = pm.Queries(fasta1m, term_size=31)
+            del fasta1m
+            plan1m, sure1m = W.plant_plan(q1m.hash_terms(1, 1), 1_000_000, terms_per_q, fsub, every=2500, docs_per_query=8)
+            for i, ix in enumerate(indexes):
+                if i in plan1m:
+                    ix.plant(*plan1m[i])
+            cur.update({"q": q1m, "n_terms": 1_000_000 * terms_per_q, "tag": cur["tag"] + "/1M"})
+            full_shard["queries_1M"] = {"setup_s": round(time.time() - t0, 2), "planted_pairs_at_or_above_threshold": sure1m}
+            for m in modes:
+                r = timed_run(m == "threshold_bound", 1, 2)
+                sm = summary(r, 2, m, None)
+                ok = ok and sm["hits"] is not None and sm["hits"] >= sure1m
+                full_shard["queries_1M"][m] = {"value": sm["value"], "unit": "k-mers/s", "ms_per_step": sm["ms_per_step"],
+                                               "hits": sm["hits"], "roofline": sm["roofline"], "roofline_narrow": sm["roofline_narrow"]}
+            cur.clear(); cur.update(saved)
+            q1m.free()
+            pm.set_option("threshold_bound", 1)
+        except Exception as e:
+            log(f"[bench] full_shard leg failed: {e!r}")
+            full_shard = dict(full_shard or {}, error=repr(e))
+            cur.clear(); cur.update(saved)
+            pm.set_option("threshold_bound", 1)
 
     ph = run_head["phase"]
     out = {

@@ -1,5 +1,7 @@
 """Randomised differential test: the HIP path vs the oracle on random index shapes,
 k-mer sizes, hash counts, thresholds, query lengths and formats (seeded, 60 cases)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,8 +9,17 @@ from helpers import build_case, doc_names, rand_seq
 
 pytestmark = pytest.mark.gpu
 
+# PM_FUZZ_EXTRA=N adds N more seeded cases to each test (from seed PM_FUZZ_OFFSET on): the wide sweeps of
+# tools/fuzz_sweep.sh; the default suite keeps its fixed 60 + 24 cases
+_EXTRA = int(os.environ.get("PM_FUZZ_EXTRA", "0"))
+_OFFSET = int(os.environ.get("PM_FUZZ_OFFSET", "100"))
 
-@pytest.mark.parametrize("seed", range(60))
+
+def _seeds(n):
+    return list(range(n)) + list(range(_OFFSET, _OFFSET + _EXTRA))
+
+
+@pytest.mark.parametrize("seed", _seeds(60))
 def test_random_case_text_identical(pm, oracle, seed):
     from phylign_amd import postprocess as P
     rng = np.random.default_rng(1000 + seed)
@@ -57,7 +68,7 @@ def test_random_case_text_identical(pm, oracle, seed):
     assert pm.query_text(ix, fasta, thr, nb_best_hits=n).decode() == P.filter_text(exp.decode(), n)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24))
 def test_random_multi_index_search_text_identical(pm, oracle, seed):
     """several random batches of different row widths in ONE search (fused launches, mixed-width
     launch, column slabs), dense and sparse hit lists, both scan modes, sync and in flight: the
@@ -85,18 +96,25 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
     exp = [oracle.query_file(c[0], fasta, thr) for c in cases]
     got = {}
     try:
-        for bound, wq in ((1, 0), (0, 0), (1, 1), (0, 2)):      # scan modes x wide-query form (auto, forced, off)
+        # scan modes x wide-query form (auto, forced, off) x its split over workgroups (auto, 3 / 7 ways) x one launch
+        # for all row widths
+        for bound, wq, split, single in ((1, 0, 0, 0), (0, 0, 0, 0), (1, 1, 0, 0), (0, 2, 0, 0), (0, 1, 3, 0), (1, 1, 7, 1),
+                                         (0, 0, 0, 1)):
             pm.set_option("threshold_bound", bound)
             pm.set_option("wide_query", wq)
+            pm.set_option("wide_query_split", split)
+            pm.set_option("single_launch", single)
             r1 = pm.search_async(ixs, q, thr, slot_base=base, nb_best_hits=n)
             r2 = pm.search_async(ixs, q, thr, slot_base=base)
-            got[(bound, wq)] = (r1.hits(), r2.hits())
+            got[(bound, wq, split, single)] = (r1.hits(), r2.hits())
     finally:
         pm.set_option("threshold_bound", 1)
         pm.set_option("wide_query", 0)
+        pm.set_option("wide_query_split", 0)
+        pm.set_option("single_launch", 0)
     for key in got:
-        assert np.array_equal(got[key][0], got[(1, 0)][0]) and np.array_equal(got[key][1], got[(1, 0)][1]), key
-    pruned, plain = got[(1, 0)]
+        assert np.array_equal(got[key][0], got[(1, 0, 0, 0)][0]) and np.array_equal(got[key][1], got[(1, 0, 0, 0)][1]), key
+    pruned, plain = got[(1, 0, 0, 0)]
     for s, ix in enumerate(ixs):
         assert pm.format_hits(ix, q, plain, slot=base + s) == exp[s]
         if n:

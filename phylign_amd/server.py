@@ -208,7 +208,12 @@ class Dispatcher(threading.Thread):
                 batch.append(j)
             groups = OrderedDict()
             for j in batch:
-                k = (j["fkey"], j["threshold"], j["nb"], j["ix"].info.term_size)
+                try:
+                    k = (j["fkey"], j["threshold"], j["nb"], j["ix"].info.term_size)
+                except Exception as e:                 # this thread must outlive any single bad job
+                    j["error"] = e
+                    j["done"].set()
+                    continue
                 groups.setdefault(k, []).append(j)
             for (_, thr, nb, k), jobs in groups.items():
                 try:
@@ -255,7 +260,7 @@ def _recv_exact(conn, n):
     return bytes(buf)
 
 
-def serve(sock_path, device=0, max_gb=0.0, coalesce_ms=0.0, preload=(), ready_fd=None):
+def serve(sock_path, device=0, max_gb=0.0, coalesce_ms=0.0, preload=()):
     from . import _lib as pm
     pm.init(device)
     free = pm.device_info()["hbm_free"]

@@ -258,8 +258,8 @@ int  pm_format_hits(const pm_index_t* idx, const pm_queries_t* q,
 int  pm_format_hits_limit(const pm_index_t* idx, const pm_queries_t* q,
                           const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
                           uint64_t limit, char** text, size_t* len);
-/* The 03_match file of one batch in one call: pm_format_hits(nb_best_hits) deflated like `gzip --fast` (level 1; as
- * consecutive gzip members, built on several threads) and written to `path` via "<path>.tmp" + rename -- what
+/* The 03_match file of one batch in one call: pm_format_hits(nb_best_hits) deflated like `gzip --fast` (level 1: pm_gzip_fast's encoder; 0, 2-9:
+ * zlib at that level; as consecutive gzip members, built on several threads) and written to `path` via "<path>.tmp" + rename -- what
  * `... | postprocess_cobs.py -n N | gzip --fast > intermediate/03_match/<batch>____<qfile>.gz` leaves (Snakefile:463-469).
  * *text_bytes / *gz_bytes (optional): sizes before / after compression. */
 int  pm_format_hits_gz(const pm_index_t* idx, const pm_queries_t* q,
@@ -271,6 +271,12 @@ int  pm_format_hits_gz(const pm_index_t* idx, const pm_queries_t* q,
 int  pm_format_hits_gz_piece(const pm_index_t* idx, const pm_queries_t* q,
                              const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits,
                              const char* path, int level, int piece, uint64_t* text_bytes, uint64_t* gz_bytes);
+/* `gzip --fast` of a result text as the stage writes it (level 1 above): the text is cut at line boundaries into ~1 MiB
+ * pieces, each becomes one gzip member (fixed-Huffman deflate; matches are found through the line structure of cobs /
+ * post-filter output: the last line with the same reference name, the previous "*" line), built on several threads.
+ * Any byte string is accepted; `gzip -dc` / xopen / Python's gzip decode the result to `text` (Snakefile:427, :468, :483
+ * only ever pipe into `gzip --fast`; scripts/filter_queries.py:46 only ever inflates).  *gz is freed with pm_free(). */
+int  pm_gzip_fast(const char* text, size_t len, char** gz, size_t* gz_len);
 /* one-shot: what `cobs query -i INDEX -f FASTA -t T` prints */
 int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
                    double threshold, int64_t nb_best_hits, char** text, size_t* len);

@@ -98,6 +98,7 @@ SYMBOLS = [
     ("pm_format_hits_limit", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_format_hits_gz", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.c_char_p, C.c_int,
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("pm_gzip_fast", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_format_hits_gz_piece", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.c_char_p, C.c_int, C.c_int,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pm_merge_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
@@ -483,6 +484,15 @@ def format_hits_gz(index: Index, queries: Queries, hits, path, slot=0, nb_best_h
     _chk(load().pm_format_hits_gz_piece(index._h, queries._h, hits.ctypes.data, hits.size, slot, nb_best_hits,
                                         os.fsencode(path), level, piece, C.byref(t), C.byref(z)))
     return t.value, z.value
+
+
+def gzip_fast(text: bytes) -> bytes:
+    """`gzip --fast` of a result text by the library's own encoder (gzip members of ~1 MiB, built in parallel)"""
+    g, n = _P(), C.c_size_t()
+    _chk(load().pm_gzip_fast(text, len(text), C.byref(g), C.byref(n)))
+    out = C.string_at(g.value, n.value)
+    load().pm_free(g)
+    return out
 
 
 def format_hits_limit(index: Index, queries: Queries, hits, slot=0, limit=0) -> bytes:

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libphylign_match.so")
-SOURCES = ["pm_kernels.hip", "pm_runtime.cpp", "pm_index.cpp", "pm_queries.cpp", "pm_search.cpp", "pm_text.cpp"]
+SOURCES = ["pm_kernels.hip", "pm_runtime.cpp", "pm_index.cpp", "pm_queries.cpp", "pm_search.cpp", "pm_text.cpp", "pm_gzfast.cpp"]
 HEADERS = ["pm_internal.h", "pm_host.h", os.path.join("..", "..", "include", "phylign_match.h")]
 
 

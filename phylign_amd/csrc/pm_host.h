@@ -152,6 +152,11 @@ void parallel_for(size_t n, const std::function<void(size_t)>& fn);
 size_t parallel_width();                    // worker threads + the caller (<= 16)
 // pm_index.cpp: pooled staging buffers of the parallel file loader (released by pm_shutdown)
 void release_stage_pool();
+void release_text_pool();                    // pm_text.cpp: the pooled text / gzip buffers of the 03_match writer
+// pm_gzfast.cpp: text[0, n) (n < 2^31) as one gzip member -- fixed-Huffman deflate, line-structured matches -- written
+// to out[0, gz_fast_bound(n)); returns the member's length
+size_t gz_fast_bound(size_t n);
+size_t gz_fast_member(const char* text, size_t n, uint8_t* out);
 // pm_queries.cpp: HBM copies of a query set on first use; device hashes per (canonicalize, num_hashes)
 int upload_queries(pm_queries* q);
 int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out);

@@ -132,6 +132,7 @@ extern "C" void pm_shutdown(void) {
         delete w;
     }
     release_stage_pool();
+    release_text_pool();
     for (auto& b : g_ctx.free_hits) (void)hipFree(b.p);
     if (g_ctx.d_fetch) (void)hipFree(g_ctx.d_fetch);
     for (auto& b : g_ctx.free_pinned) (void)hipHostFree(b.p);

@@ -10,21 +10,97 @@
 // nb_best_hits >= 0 fuses scripts/postprocess_cobs.py:16-39: header untouched,
 // each name cut to "_" + what follows its first '_', the first n lines kept plus
 // later lines whose score equals the n-th score.
-static inline void append_tab_uint_nl(std::string& out, uint64_t v) {     // "\t<v>\n"
-    char buf[24]; int n = 0;
-    do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    out.push_back('\t');
-    while (n) out.push_back(buf[--n]);
-    out.push_back('\n');
+// Text and gzip bytes are built in POOLED raw buffers: a 03_match file of a million reads is tens of MB per batch, and
+// fresh allocations of that size are mmap'ed, zero-filled and page-faulted by every formatting thread on every call
+// (measured: the same formatting took as long on 8 threads as on 1).  Buffers go back to the pool after the file is
+// written and keep their pages; the pool holds at most PM_TEXT_POOL_MB (default 1024) and is emptied by pm_shutdown.
+struct Buf { char* p = nullptr; size_t cap = 0, n = 0; };
+namespace {
+std::mutex g_tb_mu;
+std::vector<Buf> g_tb_free;
+size_t g_tb_bytes = 0;
+size_t text_pool_limit() {
+    static const size_t lim = [] { const char* e = getenv("PM_TEXT_POOL_MB"); return (size_t)(e ? atoll(e) : 1024) << 20; }();
+    return lim;
+}
+}  // namespace
+static Buf take_buf(size_t cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_tb_mu);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < g_tb_free.size(); ++i)
+            if (g_tb_free[i].cap >= cap && (best == SIZE_MAX || g_tb_free[i].cap < g_tb_free[best].cap)) best = i;
+        if (best != SIZE_MAX && g_tb_free[best].cap <= 4 * cap + (1u << 20)) {
+            Buf b = g_tb_free[best];
+            g_tb_free[best] = g_tb_free.back(); g_tb_free.pop_back();
+            g_tb_bytes -= b.cap;
+            b.n = 0;
+            return b;
+        }
+    }
+    Buf b;
+    b.cap = std::max<size_t>(cap + cap / 8, 1u << 16);          // some slack: the next call's piece is rarely the same size
+    b.p = (char*)malloc(b.cap);
+    if (!b.p) b.cap = 0;
+    return b;
+}
+static void give_buf(Buf& b) {
+    if (!b.p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_tb_mu);
+        if (g_tb_bytes + b.cap <= text_pool_limit()) {
+            g_tb_bytes += b.cap;
+            g_tb_free.push_back(b);
+            b = Buf();
+            return;
+        }
+    }
+    free(b.p);
+    b = Buf();
+}
+static void give_bufs(std::vector<Buf>& v) { for (Buf& b : v) give_buf(b); v.clear(); }
+void release_text_pool() {
+    std::lock_guard<std::mutex> lk(g_tb_mu);
+    for (Buf& b : g_tb_free) free(b.p);
+    g_tb_free.clear();
+    g_tb_bytes = 0;
 }
 
-// formats the records of queries [qa, qb) (a slice of one slot's ordered records) into `out`;
+static inline char* put_tab_uint_nl(char* w, uint64_t v) {     // "\t<v>\n"
+    char buf[24]; int n = 0;
+    do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    *w++ = '\t';
+    while (n) *w++ = buf[--n];
+    *w++ = '\n';
+    return w;
+}
+
+// formats the records of queries [qa, qb) (a slice of one slot's ordered records) into a pooled buffer;
 // returns PM_OK or an error code with the message in `err`
 static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_hit_t* mine, size_t n_mine,
-                              size_t qa, size_t qb, int64_t nb_best, uint64_t limit, std::string& out, std::string& err) {
+                              size_t qa, size_t qb, int64_t nb_best, uint64_t limit, Buf& out, std::string& err) {
     char msg[512];
     size_t p = (size_t)(std::lower_bound(mine, mine + n_mine, (uint32_t)qa,
                                          [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
+    // room: every header line, every record's name and score (an upper bound: the post-filter prints less)
+    {
+        size_t need = 64;
+        for (size_t qi = qa; qi < qb; ++qi) need += q->headers[qi].size() + 24;
+        const size_t pe = (size_t)(std::lower_bound(mine + p, mine + n_mine, (uint32_t)qb,
+                                                    [](const pm_hit_t& h, uint32_t v) { return h.query < v; }) - mine);
+        for (size_t i = p; i < pe; ++i) {
+            if (mine[i].doc == PM_DOC_COUNT) continue;
+            if (mine[i].doc >= ix->info.n_docs) {
+                snprintf(msg, sizeof msg, "hit record (query %u, doc %u) out of range for this index", mine[i].query, mine[i].doc);
+                err = msg;
+                return PM_EINVAL;
+            }
+            need += (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc]) + 12;
+        }
+        out = take_buf(need);
+        if (!out.p) { err = "out of host memory"; return PM_ENOMEM; }
+    }
+    char* w = out.p;
     for (size_t qi = qa; qi < qb; ++qi) {
         size_t e = p;
         while (e < n_mine && mine[e].query == qi) ++e;
@@ -40,17 +116,17 @@ static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_
             if (e - p > limit) e = p + (size_t)limit;
             total = e - p;
         }
-        if (!q->headerless[qi]) out.push_back('*');
+        if (!q->headerless[qi]) *w++ = '*';
         else if (nb_best >= 0) {    // the post-filter needs a '*' line first (postprocess_cobs.py:23-29 raises)
             snprintf(msg, sizeof msg, "record %zu has sequence lines before any FASTA header: the post-filter cannot parse its result", qi);
             err = msg;
             return PM_EINVAL;
         }
-        out += q->headers[qi];
-        append_tab_uint_nl(out, total);
+        memcpy(w, q->headers[qi].data(), q->headers[qi].size()); w += q->headers[qi].size();
+        w = put_tab_uint_nl(w, total);
         uint32_t min_kmers = 0;
         for (size_t i = p; i < e; ++i) {
-            if (mine[i].doc >= ix->info.n_docs) {
+            if (mine[i].doc >= ix->info.n_docs) {                 // a count record in the middle of a run: malformed input
                 snprintf(msg, sizeof msg, "hit record (query %u, doc %u) out of range for this index", mine[i].query, mine[i].doc);
                 err = msg;
                 return PM_EINVAL;
@@ -58,8 +134,8 @@ static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_
             const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
             const size_t nl = (size_t)(ix->name_off[mine[i].doc + 1] - ix->name_off[mine[i].doc] - 1);
             if (nb_best < 0) {
-                out.append(nm, nl);
-                append_tab_uint_nl(out, mine[i].score);
+                memcpy(w, nm, nl); w += nl;
+                w = put_tab_uint_nl(w, mine[i].score);
                 continue;
             }
             const int64_t rank = (int64_t)(i - p) + 1;      // 1-based like the post-filter's counter
@@ -67,7 +143,7 @@ static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_
             if (!us) {
                 // postprocess_cobs.py:16-18 turns such a line into a bare "_" (no newline) and
                 // raises on int("_") once rank >= n: an error for the whole rule
-                if (rank < nb_best) { out.push_back('_'); continue; }
+                if (rank < nb_best) { *w++ = '_'; continue; }
                 snprintf(msg, sizeof msg, "document name '%.*s' has no '_' separator (post-filter cannot parse it)", (int)nl, nm);
                 err = msg;
                 return PM_EINVAL;
@@ -77,13 +153,15 @@ static int format_query_range(const pm_index* ix, const pm_queries* q, const pm_
             else if (rank == nb_best) { keep = true; min_kmers = mine[i].score; }
             else keep = mine[i].score == min_kmers;
             if (keep) {
-                out.append(us, nl - (size_t)(us - nm));
-                append_tab_uint_nl(out, mine[i].score);
+                const size_t sl = nl - (size_t)(us - nm);
+                memcpy(w, us, sl); w += sl;
+                w = put_tab_uint_nl(w, mine[i].score);
             }
         }
         p = e;
         while (p < n_mine && mine[p].query == qi) ++p;          // records past a -l limit
     }
+    out.n = (size_t)(w - out.p);
     return PM_OK;
 }
 
@@ -102,9 +180,10 @@ extern "C" int pm_format_hits_limit(const pm_index_t* ix, const pm_queries_t* q,
     return format_impl(ix, q, hits, n_hits, slot, -1, limit, text, len);
 }
 
-// the text in consecutive pieces (one per formatting thread, each ending on a line boundary)
+// the text in consecutive pieces (one per formatting thread, each ending on a line boundary); the caller hands the
+// pieces back with give_bufs()
 static int format_parts(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
-                        int64_t nb_best, uint64_t limit, std::vector<std::string>& parts) {
+                        int64_t nb_best, uint64_t limit, std::vector<Buf>& parts) {
     if (!ix || !q || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
     const size_t nq = q->headers.size();
     // records as pm_result_hits_* deliver them are already in line order: the slot's records are
@@ -127,7 +206,7 @@ static int format_parts(const pm_index_t* ix, const pm_queries_t* q, const pm_hi
     // thread spends seconds per batch here, scripts/postprocess_cobs.py far more)
     size_t nt = std::min<size_t>(parallel_width(), (nq + n_mine / 8) / 4096);
     if (nt < 1) nt = 1;
-    parts.assign(nt, std::string());
+    parts.assign(nt, Buf());
     std::vector<std::string> errs(nt);
     std::vector<int> rcs(nt, PM_OK);
     // split by records + queries so that long hit lists spread evenly
@@ -145,34 +224,100 @@ static int format_parts(const pm_index_t* ix, const pm_queries_t* q, const pm_hi
         cutq[t] = lo;
     }
     auto work = [&](size_t t) {
-        parts[t].reserve((size_t)((double)(n_mine * 28 + nq * 24) / (double)nt * 1.1) + 64);
         rcs[t] = format_query_range(ix, q, mine, n_mine, cutq[t], cutq[t + 1], nb_best, limit, parts[t], errs[t]);
     };
     parallel_for(nt, work);
     for (size_t t = 0; t < nt; ++t)
-        if (rcs[t] != PM_OK) return fail(rcs[t], "%s", errs[t].c_str());      // the first failing query range, as a serial pass would report
+        if (rcs[t] != PM_OK) {                                   // the first failing query range, as a serial pass would report
+            give_bufs(parts);
+            return fail(rcs[t], "%s", errs[t].c_str());
+        }
     return PM_OK;
 }
 
 static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
                        int64_t nb_best, uint64_t limit, char** text, size_t* len) {
     if (!text || !len) return fail(PM_EINVAL, "bad argument");
-    std::vector<std::string> parts;
+    std::vector<Buf> parts;
     { int rc = format_parts(ix, q, hits, n_hits, slot, nb_best, limit, parts); if (rc) return rc; }
     size_t total = 0;
-    for (auto& s2 : parts) total += s2.size();
+    for (auto& s2 : parts) total += s2.n;
     char* buf = (char*)malloc(total + 1);
-    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    if (!buf) { give_bufs(parts); return fail(PM_ENOMEM, "out of host memory"); }
     size_t o = 0;
-    for (auto& s2 : parts) { memcpy(buf + o, s2.data(), s2.size()); o += s2.size(); }
+    for (auto& s2 : parts) { memcpy(buf + o, s2.p, s2.n); o += s2.n; }
     buf[total] = 0;
+    give_bufs(parts);
     *text = buf; *len = total;
+    return PM_OK;
+}
+
+// pieces of ~1 MiB that end on a line boundary (64 MiB at most, whatever the lines are): the units of the parallel deflate
+struct Chunk { const char* p; size_t n; };
+static void cut_chunks(const char* p, size_t n, std::vector<Chunk>& chunks) {
+    constexpr size_t kChunk = 1u << 20, kMax = 64u << 20;
+    size_t o = 0;
+    while (o < n) {
+        size_t e = std::min(n, o + kChunk);
+        if (e < n) {
+            const size_t lim = std::min(n, o + kMax);
+            const void* nl = memchr(p + e, '\n', lim - e);
+            e = nl ? (size_t)((const char*)nl - p) + 1 : lim;
+        }
+        chunks.push_back({p + o, e - o});
+        o = e;
+    }
+}
+// chunks -> gzip members in pooled buffers (level 1: this library's `gzip --fast`, pm_gzfast.cpp; else zlib at that level)
+static int deflate_chunks(const std::vector<Chunk>& chunks, int level, std::vector<Buf>& members) {
+    members.assign(chunks.size(), Buf());
+    std::vector<int> zrc(chunks.size(), Z_OK);
+    auto deflate_one = [&](size_t i) {
+        Buf& out = members[i];
+        if (level == 1) {
+            out = take_buf(gz_fast_bound(chunks[i].n));
+            if (!out.p) { zrc[i] = Z_MEM_ERROR; return; }
+            out.n = gz_fast_member(chunks[i].p, chunks[i].n, (uint8_t*)out.p);
+            return;
+        }
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        int rc = deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);      // 15 + 16: gzip container
+        if (rc != Z_OK) { zrc[i] = rc; return; }
+        out = take_buf(deflateBound(&z, (uLong)chunks[i].n) + 64);
+        if (!out.p) { zrc[i] = Z_MEM_ERROR; deflateEnd(&z); return; }
+        z.next_in = (Bytef*)const_cast<char*>(chunks[i].p); z.avail_in = (uInt)chunks[i].n;
+        z.next_out = (Bytef*)out.p; z.avail_out = (uInt)out.cap;
+        rc = deflate(&z, Z_FINISH);
+        if (rc != Z_STREAM_END) zrc[i] = rc == Z_OK ? Z_BUF_ERROR : rc;
+        else out.n = z.total_out;
+        deflateEnd(&z);
+    };
+    parallel_for(chunks.size(), deflate_one);
+    for (int rc : zrc) if (rc != Z_OK) { give_bufs(members); return fail(rc == Z_MEM_ERROR ? PM_ENOMEM : PM_EIO, "deflate failed (%d)", rc); }
+    return PM_OK;
+}
+extern "C" int pm_gzip_fast(const char* text, size_t len, char** gz, size_t* gz_len) {
+    if ((!text && len) || !gz || !gz_len) return fail(PM_EINVAL, "bad argument");
+    std::vector<Chunk> chunks;
+    cut_chunks(text, len, chunks);
+    if (chunks.empty()) chunks.push_back({"", 0});
+    std::vector<Buf> members;
+    { int rc = deflate_chunks(chunks, 1, members); if (rc) return rc; }
+    size_t total = 0;
+    for (auto& m2 : members) total += m2.n;
+    char* buf = (char*)malloc(total ? total : 1);
+    if (!buf) { give_bufs(members); return fail(PM_ENOMEM, "out of host memory"); }
+    size_t o = 0;
+    for (auto& m2 : members) { memcpy(buf + o, m2.p, m2.n); o += m2.n; }
+    give_bufs(members);
+    *gz = buf; *gz_len = total;
     return PM_OK;
 }
 
 // The 03_match FILE of one batch in one call: what `run_cobs_streaming.sh ... | postprocess_cobs.py -n N | gzip --fast >
 // <batch>____<qfile>.gz` leaves on disk (Snakefile:463-469).  The text is formatted on several threads (as above), cut at
-// line boundaries into chunks of ~4 MiB that are deflated in parallel as consecutive gzip MEMBERS (a multi-member file is
+// line boundaries into chunks of ~1 MiB that are deflated in parallel as consecutive gzip MEMBERS (a multi-member file is
 // a valid gzip stream: `gzip -dc`, xopen and Python's gzip decode it to the same bytes -- scripts/filter_queries.py:46
 // reads through xopen), and written to "<path>.tmp" + rename.  Nothing of it passes through the caller.
 static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
@@ -196,61 +341,33 @@ static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, cons
                                uint32_t slot, int64_t nb_best, const char* path, int level, int piece,
                                uint64_t* text_bytes, uint64_t* gz_bytes) {
     if (!path || level < 0 || level > 9) return fail(PM_EINVAL, "bad argument");
-    std::vector<std::string> parts;
+    std::vector<Buf> parts;
     { int rc = format_parts(ix, q, hits, n_hits, slot, nb_best, 0, parts); if (rc) return rc; }
-    struct Chunk { const char* p; size_t n; };
     std::vector<Chunk> chunks;
-    constexpr size_t kChunk = 4u << 20;
     uint64_t total = 0;
-    for (const std::string& s2 : parts) {
-        total += s2.size();
-        size_t o = 0;
-        while (o < s2.size()) {
-            size_t e = std::min(s2.size(), o + kChunk);
-            if (e < s2.size()) {
-                const void* nl = memchr(s2.data() + e, '\n', s2.size() - e);
-                e = nl ? (size_t)((const char*)nl - s2.data()) + 1 : s2.size();
-            }
-            chunks.push_back({s2.data() + o, e - o});
-            o = e;
-        }
+    for (const Buf& s2 : parts) {
+        total += s2.n;
+        cut_chunks(s2.p, s2.n, chunks);
     }
     if (chunks.empty()) chunks.push_back({"", 0});                    // an empty text is one empty member
-    std::vector<std::string> members(chunks.size());
-    std::vector<int> zrc(chunks.size(), Z_OK);
-    auto deflate_one = [&](size_t i) {
-        {
-            z_stream z;
-            memset(&z, 0, sizeof z);
-            int rc = deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);      // 15 + 16: gzip container
-            if (rc != Z_OK) { zrc[i] = rc; return; }
-            std::string& out = members[i];
-            out.resize(deflateBound(&z, (uLong)chunks[i].n) + 64);
-            z.next_in = (Bytef*)const_cast<char*>(chunks[i].p); z.avail_in = (uInt)chunks[i].n;
-            z.next_out = (Bytef*)&out[0]; z.avail_out = (uInt)out.size();
-            rc = deflate(&z, Z_FINISH);
-            if (rc != Z_STREAM_END) zrc[i] = rc == Z_OK ? Z_BUF_ERROR : rc;
-            else out.resize(z.total_out);
-            deflateEnd(&z);
-        }
-    };
-    parallel_for(chunks.size(), deflate_one);
-    for (int rc : zrc) if (rc != Z_OK) return fail(PM_EIO, "zlib deflate failed (%d)", rc);
+    std::vector<Buf> members;
+    { int rc = deflate_chunks(chunks, level, members); give_bufs(parts); if (rc) return rc; }
     const std::string tmp = std::string(path) + ".tmp";
     const bool append = piece == 2 || piece == 3, finish = piece == 0 || piece == 3;
     int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | (append ? O_APPEND : O_TRUNC), 0644);
-    if (fd < 0) return fail(PM_EIO, "cannot %s '%s': %s", append ? "append to" : "create", tmp.c_str(), strerror(errno));
+    if (fd < 0) { give_bufs(members); return fail(PM_EIO, "cannot %s '%s': %s", append ? "append to" : "create", tmp.c_str(), strerror(errno)); }
     uint64_t gz = 0;
     int e = 0;
-    for (const std::string& m2 : members) {
-        const char* p2 = m2.data(); size_t left = m2.size();
+    for (const Buf& m2 : members) {
+        const char* p2 = m2.p; size_t left = m2.n;
         while (left && !e) {
             ssize_t w = write(fd, p2, left);
             if (w < 0) { if (errno == EINTR) continue; e = errno; break; }
             p2 += w; left -= (size_t)w;
         }
-        gz += m2.size();
+        gz += m2.n;
     }
+    give_bufs(members);
     if (close(fd) != 0 && !e) e = errno;
     if (e) { (void)unlink(tmp.c_str()); return fail(PM_EIO, "writing '%s': %s", tmp.c_str(), strerror(e)); }
     if (finish && rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
@@ -301,8 +418,39 @@ struct pm_merge {
     const pm_queries* q = nullptr;
     uint32_t keep = 0;
     std::vector<MergeBatch> batches;
-    std::unordered_map<std::string, uint32_t> by_name;        // query name (first word) -> record index
-    std::vector<std::string> qnames;
+    // query name (readfq: the header up to its first space) -> record index.  A flat open-addressing table over views
+    // into the query set's header strings (the query set outlives the merge): a million std::string keys in an
+    // unordered_map cost 0.2-0.6 s to build, serially, before the first search of the stage could start.
+    std::vector<const char*> qname_p;
+    std::vector<uint32_t> qname_n;
+    std::vector<uint32_t> table;                              // record index or kEmpty
+    uint32_t mask = 0;
+    std::vector<uint32_t> canon;                              // canon[i]: the record a lookup of query i's name finds (dict: the last one wins)
+    static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    static uint64_t hash_name(const char* p, size_t n) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        size_t j = 0;
+        for (; j + 8 <= n; j += 8) { uint64_t w; memcpy(&w, p + j, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+        if (j < n) { uint64_t w = 0; memcpy(&w, p + j, n - j); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+        return h * 0xC4CEB9FE1A85EC53ull;
+    }
+    // the table is 2^region_bits regions (top bits of the hash), probing wraps inside a region: regions are filled by
+    // different threads, each in record order (so "the last one wins" holds)
+    uint32_t region_bits = 0;
+    uint32_t slot0(uint64_t h, uint32_t* base, uint32_t* rmask) const {
+        const uint32_t rsize = (mask + 1u) >> region_bits;
+        *rmask = rsize - 1u;
+        *base = region_bits ? (uint32_t)(h >> (64 - region_bits)) * rsize : 0u;
+        return (uint32_t)(h >> 16) & *rmask;
+    }
+    uint32_t lookup(const char* p, size_t n) const {           // kEmpty: no such query
+        uint32_t base, rmask;
+        for (uint32_t s2 = slot0(hash_name(p, n), &base, &rmask);; s2 = (s2 + 1) & rmask) {
+            const uint32_t r = table[base + s2];
+            if (r == kEmpty) return kEmpty;
+            if (qname_n[r] == n && memcmp(qname_p[r], p, n) == 0) return r;
+        }
+    }
     std::vector<std::vector<MergeItem>> items;
     std::vector<uint32_t> floor_;
     std::mutex mu;                                  // pm_merge_add may be called from a consumer thread pool
@@ -360,13 +508,54 @@ extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t*
     pm_merge* m = new pm_merge();
     m->q = q; m->keep = keep;
     const size_t nq = q->headers.size();
-    m->items.resize(nq); m->floor_.assign(nq, 0); m->qnames.resize(nq);
-    for (size_t i = 0; i < nq; ++i) {
-        // readfq name: the header up to its first space (scripts/filter_queries.py:80)
-        const std::string& h = q->headers[i];
-        m->qnames[i] = h.substr(0, h.find(' '));
-        m->by_name[m->qnames[i]] = (uint32_t)i;        // duplicates: the last record wins, as in a dict
+    if (nq >= 0x7FFFFFFFull) { delete m; return fail(PM_ERANGE, "too many queries for one merge"); }
+    m->items.resize(nq); m->floor_.assign(nq, 0);
+    m->qname_p.resize(nq); m->qname_n.resize(nq); m->canon.resize(nq);
+    size_t cap = 16;
+    while (cap < 2 * nq) cap <<= 1;
+    if (nq >= (1u << 16)) { cap <<= 1; m->region_bits = 4; }      // regions at a quarter load: none can fill up
+    m->table.assign(cap, pm_merge::kEmpty);
+    m->mask = (uint32_t)(cap - 1);
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(parallel_width(), nq / 65536));
+    std::vector<uint64_t> hashes(nq);
+    parallel_for(nt, [&](size_t t) {
+        for (size_t i = nq * t / nt; i < nq * (t + 1) / nt; ++i) {
+            // readfq name: the header up to its first space (scripts/filter_queries.py:80)
+            const std::string& h = q->headers[i];
+            const void* sp = memchr(h.data(), ' ', h.size());
+            m->qname_p[i] = h.data();
+            m->qname_n[i] = (uint32_t)(sp ? (size_t)((const char*)sp - h.data()) : h.size());
+            hashes[i] = pm_merge::hash_name(m->qname_p[i], m->qname_n[i]);
+        }
+    });
+    for (;;) {
+        const size_t regions = (size_t)1 << m->region_bits;
+        std::atomic<bool> full(false);
+        parallel_for(regions, [&](size_t r) {                   // duplicates: the last record wins, as in a dict
+            size_t used = 0;
+            for (size_t i = 0; i < nq; ++i) {
+                if (m->region_bits && (hashes[i] >> (64 - m->region_bits)) != r) continue;
+                uint32_t base, rmask;
+                const char* p = m->qname_p[i]; const size_t n = m->qname_n[i];
+                for (uint32_t s2 = m->slot0(hashes[i], &base, &rmask);; s2 = (s2 + 1) & rmask) {
+                    const uint32_t o = m->table[base + s2];
+                    if (o == pm_merge::kEmpty) {
+                        if (++used > rmask) { full.store(true); return; }       // would leave no empty slot: probing needs one
+                        m->table[base + s2] = (uint32_t)i;
+                        break;
+                    }
+                    if (m->qname_n[o] == n && memcmp(m->qname_p[o], p, n) == 0) { m->table[base + s2] = (uint32_t)i; break; }
+                }
+            }
+        });
+        if (!full.load()) break;
+        // names whose hashes crowd one region (never seen with real read names): one region, at most half full
+        m->region_bits = 0;
+        std::fill(m->table.begin(), m->table.end(), pm_merge::kEmpty);
     }
+    parallel_for(nt, [&](size_t t) {
+        for (size_t i = nq * t / nt; i < nq * (t + 1) / nt; ++i) m->canon[i] = m->lookup(m->qname_p[i], m->qname_n[i]);
+    });
     *out = m;
     return PM_OK;
 }
@@ -433,12 +622,14 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
         if (p == e) continue;
         // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
         // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
-        const std::string& h = m->q->headers[qi];
-        std::string key = h.substr(0, h.find('\t'));
-        key = key.substr(0, key.find(' '));
-        auto it = m->by_name.find(key);
-        if (it == m->by_name.end()) return fail(PM_EINVAL, "query '%s' of batch %s is not in the query file", key.c_str(), batch);
-        const uint32_t target = it->second;
+        // (a name holds no TAB in practice: then that text is the query's own name and the lookup is canon[])
+        uint32_t target = m->canon[qi];
+        if (const void* tab = memchr(m->qname_p[qi], '\t', m->qname_n[qi])) {
+            const size_t kn = (size_t)((const char*)tab - m->qname_p[qi]);
+            target = m->lookup(m->qname_p[qi], kn);
+            if (target == pm_merge::kEmpty)
+                return fail(PM_EINVAL, "query '%.*s' of batch %s is not in the query file", (int)kn, m->qname_p[qi], batch);
+        }
         std::vector<MergeItem>& v = m->items[target];
         const size_t before = v.size();
         uint32_t nth = 0;
@@ -502,12 +693,12 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
             if (!tab || !parse_int(nb, ne ? ne : e, &n))
                 return fail(PM_EINVAL, "batch %s line %zu: query header without an integer match count", batch, lineno);
             const char* qe = (const char*)memchr(b + 1, ' ', (size_t)(tab - (b + 1)));
-            const std::string qname(b + 1, (size_t)((qe ? qe : tab) - (b + 1)));
-            auto it = m->by_name.find(qname);
-            if (it == m->by_name.end()) return fail(PM_EINVAL, "query '%s' of batch %s is not in the query file", qname.c_str(), batch);
+            const size_t qn = (size_t)((qe ? qe : tab) - (b + 1));
+            const uint32_t found = m->lookup(b + 1, qn);
+            if (found == pm_merge::kEmpty) return fail(PM_EINVAL, "query '%.*s' of batch %s is not in the query file", (int)qn, b + 1, batch);
             // match lines ahead of the first header join the first query's list: the reference's reader only empties
             // its buffer when it has a query to yield (scripts/filter_queries.py:52-56; pinned by a captured fixture)
-            blocks.push_back({it->second, have_header ? recs.size() : 0});
+            blocks.push_back({found, have_header ? recs.size() : 0});
             have_header = true;
             continue;
         }
@@ -578,59 +769,79 @@ extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n
     return PM_OK;
 }
 
-// The FASTA text in `nt` consecutive pieces, built on `nt` threads (query ranges are independent).
-static void merge_emit_pieces(const pm_merge* m, std::vector<std::string>& parts) {
+// The 04_filter FASTA in blocks of records: exact sizes first (the text is a concatenation of known strings), then every
+// block is formatted straight to its place -- into the caller's buffer, or through a pooled scratch buffer and
+// pwrite() into the file -- on several threads.  Nothing the size of the output is allocated, touched twice or copied.
+struct EmitPlan {
+    std::vector<uint32_t> recs;           // records in output order
+    std::vector<size_t> first;            // block b covers recs[first[b], first[b + 1])
+    std::vector<uint64_t> off;            // byte offset of block b; off.back() = total
+};
+static void merge_emit_plan(const pm_merge* m, EmitPlan& pl) {
     const pm_queries* q = m->q;
+    const size_t nq = q->headers.size();
     // dict semantics of the consumer: one record per distinct name, at the position of its
     // first occurrence, with the sequence of its last occurrence
-    std::vector<uint32_t> recs;
-    recs.reserve(q->headers.size());
+    pl.recs.reserve(nq);
     {
-        std::vector<char> seen(q->headers.size(), 0);
-        for (size_t i = 0; i < q->headers.size(); ++i) {
-            const uint32_t rec = m->by_name.at(m->qnames[i]);
+        std::vector<char> seen(nq, 0);
+        for (size_t i = 0; i < nq; ++i) {
+            const uint32_t rec = m->canon[i];
             if (seen[rec]) continue;
             seen[rec] = 1;
-            recs.push_back(rec);
+            pl.recs.push_back(rec);
         }
     }
-    size_t nt = std::min<size_t>(parallel_width(), recs.size() / 8192);
-    if (nt < 1) nt = 1;
-    parts.assign(nt, std::string());
-    auto work = [&](size_t t) {
-        std::string& out = parts[t];
-        const size_t a = recs.size() * t / nt, b = recs.size() * (t + 1) / nt;
-        size_t guess = 0;
-        for (size_t k = a; k < b; ++k)
-            guess += m->qnames[recs[k]].size() + 4 + (size_t)(q->seq_off[recs[k] + 1] - q->seq_off[recs[k]]) + m->items[recs[k]].size() * 16;
-        out.reserve(guess);
-        for (size_t k = a; k < b; ++k) {
-            const uint32_t rec = recs[k];
-            out.push_back('>'); out += m->qnames[rec]; out.push_back(' ');
-            const std::vector<MergeItem>& v = m->items[rec];
-            for (size_t j = 0; j < v.size(); ++j) {
-                if (j) out.push_back(',');
-                size_t rl; const char* r = m->ref(v[j], &rl);
-                out.append(r, rl);
+    constexpr size_t kBlock = 4096;
+    const size_t nb = (pl.recs.size() + kBlock - 1) / kBlock;
+    pl.first.resize(nb + 1);
+    for (size_t b = 0; b <= nb; ++b) pl.first[b] = std::min(pl.recs.size(), b * kBlock);
+    pl.off.assign(nb + 1, 0);
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(parallel_width(), nb / 4));
+    parallel_for(nt, [&](size_t t) {
+        for (size_t b = nb * t / nt; b < nb * (t + 1) / nt; ++b) {
+            uint64_t bytes = 0;
+            for (size_t k = pl.first[b]; k < pl.first[b + 1]; ++k) {
+                const uint32_t rec = pl.recs[k];
+                const std::vector<MergeItem>& v = m->items[rec];
+                bytes += 1 + m->qname_n[rec] + 1 + (v.empty() ? 0 : v.size() - 1) + 1 + (uint64_t)(q->seq_off[rec + 1] - q->seq_off[rec]) + 1;
+                for (const MergeItem& it : v) { size_t rl; (void)m->ref(it, &rl); bytes += rl; }
             }
-            out.push_back('\n');
-            out.append(q->seqs, (size_t)q->seq_off[rec], (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]));
-            out.push_back('\n');
+            pl.off[b + 1] = bytes;
         }
-    };
-    parallel_for(nt, work);
+    });
+    for (size_t b = 0; b < nb; ++b) pl.off[b + 1] += pl.off[b];
+}
+static char* merge_emit_block(const pm_merge* m, const EmitPlan& pl, size_t b, char* w) {
+    const pm_queries* q = m->q;
+    for (size_t k = pl.first[b]; k < pl.first[b + 1]; ++k) {
+        const uint32_t rec = pl.recs[k];
+        *w++ = '>'; memcpy(w, m->qname_p[rec], m->qname_n[rec]); w += m->qname_n[rec]; *w++ = ' ';
+        const std::vector<MergeItem>& v = m->items[rec];
+        for (size_t j = 0; j < v.size(); ++j) {
+            if (j) *w++ = ',';
+            size_t rl; const char* r = m->ref(v[j], &rl);
+            memcpy(w, r, rl); w += rl;
+        }
+        *w++ = '\n';
+        const size_t sl = (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]);
+        memcpy(w, q->seqs.data() + q->seq_off[rec], sl); w += sl;
+        *w++ = '\n';
+    }
+    return w;
 }
 
 extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
     if (!m || !text || !len) return fail(PM_EINVAL, "bad argument");
-    std::vector<std::string> parts;
-    merge_emit_pieces(m, parts);
-    size_t total = 0;
-    for (auto& s2 : parts) total += s2.size();
+    EmitPlan pl;
+    merge_emit_plan(m, pl);
+    const size_t total = (size_t)pl.off.back(), nb = pl.first.size() - 1;
     char* buf = (char*)malloc(total + 1);
     if (!buf) return fail(PM_ENOMEM, "out of host memory");
-    size_t o = 0;
-    for (auto& s2 : parts) { memcpy(buf + o, s2.data(), s2.size()); o += s2.size(); }
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(parallel_width(), nb / 4));
+    parallel_for(nt, [&](size_t t) {
+        for (size_t b = nb * t / nt; b < nb * (t + 1) / nt; ++b) merge_emit_block(m, pl, b, buf + pl.off[b]);
+    });
     buf[total] = 0;
     *text = buf; *len = total;
     return PM_OK;
@@ -641,29 +852,42 @@ extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
 // is hundreds of MB that need not pass through the caller.
 extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes) {
     if (!m || !path) return fail(PM_EINVAL, "bad argument");
-    std::vector<std::string> parts;
-    merge_emit_pieces(m, parts);
+    EmitPlan pl;
+    merge_emit_plan(m, pl);
+    const size_t nb = pl.first.size() - 1;
     const std::string tmp = std::string(path) + ".tmp";
     int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) return fail(PM_EIO, "cannot create '%s': %s", tmp.c_str(), strerror(errno));
-    std::vector<uint64_t> off(parts.size() + 1, 0);
-    for (size_t t = 0; t < parts.size(); ++t) off[t + 1] = off[t] + parts[t].size();
-    std::vector<int> errs(parts.size(), 0);
-    auto wr = [&](size_t t) {
-        const char* p = parts[t].data(); size_t left = parts[t].size(); uint64_t o = off[t];
-        while (left) {
-            ssize_t w = pwrite(fd, p, left, (off_t)o);
-            if (w < 0) { if (errno == EINTR) continue; errs[t] = errno; return; }
-            p += w; left -= (size_t)w; o += (uint64_t)w;
+    // a worker formats runs of blocks of ~4 MB into one pooled scratch buffer and writes each at its offset
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(parallel_width(), nb / 4));
+    std::vector<int> errs(nt, 0);
+    parallel_for(nt, [&](size_t t) {
+        const size_t b0 = nb * t / nt, b1 = nb * (t + 1) / nt;
+        Buf scratch;
+        for (size_t b = b0; b < b1 && !errs[t];) {
+            size_t e = b + 1;
+            while (e < b1 && pl.off[e + 1] - pl.off[b] <= (4u << 20)) ++e;
+            const size_t need = (size_t)(pl.off[e] - pl.off[b]);
+            if (scratch.cap < need) { give_buf(scratch); scratch = take_buf(need); }
+            if (!scratch.p) { errs[t] = ENOMEM; break; }
+            char* w = scratch.p;
+            for (size_t k = b; k < e; ++k) w = merge_emit_block(m, pl, k, w);
+            const char* p = scratch.p; size_t left = need; uint64_t o = pl.off[b];
+            while (left) {
+                ssize_t wr = pwrite(fd, p, left, (off_t)o);
+                if (wr < 0) { if (errno == EINTR) continue; errs[t] = errno; break; }
+                p += wr; left -= (size_t)wr; o += (uint64_t)wr;
+            }
+            b = e;
         }
-    };
-    parallel_for(parts.size(), wr);
+        give_buf(scratch);
+    });
     int e = 0;
     for (int x : errs) if (x) e = x;
     if (close(fd) != 0 && !e) e = errno;
     if (e) { (void)unlink(tmp.c_str()); return fail(PM_EIO, "writing '%s': %s", tmp.c_str(), strerror(e)); }
     if (rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
-    if (bytes) *bytes = off.back();
+    if (bytes) *bytes = pl.off.back();
     return PM_OK;
 }
 

@@ -1,7 +1,7 @@
 """Parallel `gzip --fast` for the 03_match files (Snakefile:468 pipes the post-filtered
 text through `gzip --fast`).  The text is cut at line boundaries into chunks that are
-deflated on a thread pool (zlib releases the GIL) and written as consecutive gzip
-MEMBERS: a multi-member file is a valid gzip stream -- `gzip -dc`, Python's gzip /
+deflated in parallel (level 1: the library's own encoder, pm_gzip_fast; other levels: zlib
+on a thread pool, which releases the GIL) and written as consecutive gzip MEMBERS: a multi-member file is a valid gzip stream -- `gzip -dc`, Python's gzip /
 xopen (scripts/filter_queries.py:27-66 reads through xopen) decode it to the same
 bytes -- so the consumer side is unchanged."""
 import os
@@ -31,6 +31,9 @@ def split_lines(text, chunk=CHUNK):
 
 def compress(text, level=1, threads=None, pool=None):
     """gzip bytes of `text` (level 1 = `gzip --fast`); several members when the text is long"""
+    if level == 1:
+        from . import _lib as pm
+        return pm.gzip_fast(bytes(text))
     parts = split_lines(text) or [b""]
     if len(parts) == 1:
         return _member(parts[0], level)

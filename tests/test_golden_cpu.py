@@ -532,6 +532,78 @@ def test_parallel_gzip_members_decode_like_gzip_fast(tmp_path):
         assert not (tmp_path / "x.gz.tmp").exists()
 
 
+def test_fast_gzip_encoder_streams_decode_to_their_input(tmp_path):
+    """pm_gzip_fast (the level-1 encoder of the 03_match writer: fixed-Huffman deflate with line-structured
+    matches): every stream decodes, with Python's gzip and the gzip CLI, to exactly the bytes that went in --
+    result-shaped text, binary noise (9-bit literals), very long lines (matches of 258, distances up to and
+    beyond the 32 KiB window), repeated names near and far, no trailing newline, more than one member"""
+    import gzip
+    import subprocess
+    from phylign_amd import _lib as pm
+    rng = np.random.default_rng(61)
+    cases = [b"", b"\n", b"a", b"abc\n" * 3, b"\xff\x90\x8f" * 1000, bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),
+             b"x" * 100000 + b"\n" + b"x" * 100000, (b"y" * 40000 + b"\n") * 5, (b"z" * 32767 + b"\n") * 3, (b"w" * 32768 + b"\n") * 3,
+             b"_SAM1\t5\n" * 9000, b"".join(b"*read%d\t0\n" % i for i in range(250000))]
+    for _ in range(150):
+        names = [b"_SAM%07d" % rng.integers(0, 10**7) for _ in range(int(rng.integers(1, 60)))]
+        lines = []
+        for i in range(int(rng.integers(1, 500))):
+            r = rng.random()
+            if r < 0.3:
+                lines.append(b"*read%d c\t%d" % (i * int(rng.integers(1, 3)), rng.integers(0, 50)))
+            elif r < 0.9:
+                lines.append(names[int(rng.integers(0, len(names)))] + b"\t%d" % rng.integers(80, 121))
+            else:
+                lines.append(bytes(rng.integers(0, 256, int(rng.integers(0, 700)), dtype=np.uint8)).replace(b"\n", b" "))
+        cases.append(b"\n".join(lines) + (b"\n" if rng.random() < 0.8 else b""))
+    for i, t in enumerate(cases):
+        g = pm.gzip_fast(t)
+        assert gzip.decompress(g) == t, i
+    big = cases[-1] * 3000                               # several members
+    g = pm.gzip_fast(big)
+    assert g.count(b"\x1f\x8b\x08\x00") >= 2 and gzip.decompress(g) == big
+    p = tmp_path / "x.gz"
+    p.write_bytes(g)
+    assert subprocess.run(["gzip", "-dc", str(p)], capture_output=True, check=True).stdout == big
+    assert subprocess.run(["gzip", "-t", str(p)]).returncode == 0
+
+
+def test_native_merge_name_table_at_scale_keeps_dict_semantics(tmp_path):
+    """100 k query names (the regioned, thread-built name table of pm_merge_create) with duplicates: a lookup finds the
+    LAST record of a name, the FASTA has one record per distinct name at its first position -- against the Python
+    mirror of scripts/filter_queries.py (itself pinned by fixtures captured from the reference)"""
+    import gzip
+    import io
+    from phylign_amd import _lib as pm
+    from phylign_amd import filter_queries as F
+    rng = np.random.default_rng(62)
+    nq = 100000
+    qn = [f"r{i}" for i in range(nq)]
+    for i in rng.choice(nq, size=300, replace=False):
+        qn[int(i)] = qn[int(rng.integers(0, nq))]                     # duplicates, some of them chains
+    assert len(set(qn)) < nq
+    fasta = "".join(f">{n} x\n{'ACGT' * 8 + 'ACGTACGTA'[: 1 + i % 9]}\n" for i, n in enumerate(qn)).encode()
+    q = pm.Queries(fasta, term_size=31)
+    ix = pm.Index.from_names([f"{d:04x}_S{d}" for d in range(50)])
+    hit_q = np.sort(rng.choice(nq, size=5000, replace=False)).astype(np.uint32)
+    rec = np.zeros(len(hit_q) * 2, dtype=pm.HIT_DTYPE)
+    rec["query"] = np.repeat(hit_q, 2)
+    rec["doc"] = np.tile(np.array([3, 7], dtype=np.uint32), len(hit_q))
+    rec["score"] = np.tile(np.array([9, 8], dtype=np.uint32), len(hit_q))
+    m = pm.Merge(q, 3)
+    m.add("b1", ix, rec, slot=0)
+    qf, mf = tmp_path / "q.fa", tmp_path / "b1____q.gz"
+    qf.write_bytes(fasta)
+    with gzip.open(mf, "wb", compresslevel=1) as g:
+        g.write(pm.format_hits(ix, q, rec, slot=0, nb_best_hits=3))
+    out = io.StringIO()
+    F.filter_files(str(qf), [str(mf)], 3, out)
+    assert m.emit().decode() == out.getvalue()
+    assert out.getvalue().count(">") == len(set(qn))
+    n = m.emit_to(str(tmp_path / "f.fa"))
+    assert (tmp_path / "f.fa").read_bytes().decode() == out.getvalue() and n == len(out.getvalue())
+
+
 def test_header_reader_survives_corrupted_input(oracle):
     """classic / compact header bytes with random flips, truncations and insertions: the product
     reader either reports PM_EFORMAT / PM_EIO-style errors or returns a consistent handle -- it never

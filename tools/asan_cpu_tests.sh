@@ -10,7 +10,7 @@ if [ "$kind" = thread ]; then san=thread; rt=tsan; else san=address,undefined; r
 out=${TMPDIR:-/tmp}/pm_$rt
 mkdir -p "$out"
 cd "$(dirname "$0")/../phylign_amd/csrc"
-for f in pm_runtime pm_index pm_queries pm_search pm_text; do
+for f in pm_runtime pm_index pm_queries pm_search pm_text pm_gzfast; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=$san -fno-omit-frame-pointer \
       -Wno-option-ignored -x hip -c $f.cpp -o "$out/$f.o" 2>/dev/null &
 done

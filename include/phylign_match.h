@@ -37,6 +37,7 @@ typedef struct pm_index   pm_index_t;    /* one phylogenetic batch index, reside
 typedef struct pm_queries pm_queries_t;  /* a parsed query FASTA, resident in HBM */
 typedef struct pm_result  pm_result_t;   /* hits of one pm_search call */
 typedef struct pm_merge   pm_merge_t;    /* 04_filter state: best matches per query across batches */
+typedef struct pm_slice   pm_slice_t;    /* the records of one index of a search on the host (pooled pinned memory) */
 
 /* Row layout policy in HBM (DESIGN.md "Data layout"). */
 #define PM_LAYOUT_AUTO     0  /* line-aligned stride if it fits, else compact */
@@ -239,6 +240,13 @@ int  pm_result_hits_into(const pm_result_t* r, pm_hit_t* out, uint64_t capacity,
 /* records on the host ordered by (slot, query, score desc, doc asc);
  * library-owned pinned memory, valid until pm_result_free */
 int  pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n);
+/* the ordered records of ONE index of the search (slot = its position in the idx array, 0 ... n_idx - 1) read back on
+ * their own: what one 03_match file / one pm_merge_add needs (one `cobs query` job's stdout: Snakefile:463-469).  The
+ * host half of a stage takes a search apart batch by batch, from several threads; the records of a batch come in a
+ * pooled pinned buffer that goes back to the pool with pm_slice_free() (pinning the memory for ALL records of a
+ * million-read search costs more than copying them).  Thread-safe. */
+int  pm_result_slot_hits(pm_result_t* r, uint32_t slot, const pm_hit_t** hits, uint64_t* n, pm_slice_t** slice);
+void pm_slice_free(pm_slice_t* slice);
 void pm_result_free(pm_result_t* r);
 /* orders records in place by (slot, query, score desc, doc asc): the order of
  * cobs' result lines; for records gathered from other ranks */

@@ -98,6 +98,8 @@ SYMBOLS = [
     ("pm_format_hits_limit", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_format_hits_gz", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.c_char_p, C.c_int,
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("pm_result_slot_hits", C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(_P)]),
+    ("pm_slice_free", None, [_P]),
     ("pm_gzip_fast", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_format_hits_gz_piece", C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_int64, C.c_char_p, C.c_int, C.c_int,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -381,10 +383,47 @@ class Result:
         view = np.frombuffer(buf, dtype=HIT_DTYPE)
         return view.copy() if copy else view
 
+    def slot_hits(self, slot):
+        """the ordered records of ONE index of the search (position `slot` in the index list), read back on their own
+        into a pooled pinned buffer: a Slice whose .hits view is valid until its free() (or `with`)"""
+        p, n, tok = _P(), C.c_uint64(), _P()
+        _chk(load().pm_result_slot_hits(self._h, slot, C.byref(p), C.byref(n), C.byref(tok)))
+        return Slice(p.value, n.value, tok)
+
     def free(self):
         if self._h:
             load().pm_result_free(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Slice:
+    """records of one index of a search on the host (Result.slot_hits)"""
+
+    def __init__(self, ptr, n, tok):
+        self._tok = tok
+        if n:
+            buf = (C.c_char * (n * HIT_DTYPE.itemsize)).from_address(ptr)
+            self.hits = np.frombuffer(buf, dtype=HIT_DTYPE)
+        else:
+            self.hits = np.empty(0, dtype=HIT_DTYPE)
+
+    def free(self):
+        if self._tok:
+            self.hits = np.empty(0, dtype=HIT_DTYPE)
+            load().pm_slice_free(self._tok)
+            self._tok = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
 
     def __del__(self):
         try:

@@ -130,6 +130,7 @@ struct pm_result {
     std::atomic<bool> ordered{false};              // double-checked under g_order_mu
     HitBuf d_ord{nullptr, 0};
     uint64_t n_out = 0;
+    std::vector<uint64_t> slot_first;             // first ordered record of every index of the search (+ the end): the slices of pm_result_slot_hits
     // host copy (pinned, pooled)
     PinBuf host{nullptr, 0};
     bool host_ready = false;
@@ -681,9 +682,13 @@ static int ensure_ordered(pm_result* r) {
     uint64_t o = 0;
     size_t np = 0, k = 0;
     std::vector<uint4> m_groups, m_runs;
+    r->slot_first.assign(r->idx.size() + 1, 0);
+    size_t next_slot = 0;                          // slots up to here have their first record noted
     while (k < dir.size()) {
         size_t e = k + 1;
         while (e < dir.size() && dir[e].slot == dir[k].slot && dir[e].query == dir[k].query) ++e;
+        for (const size_t s_rel = (size_t)(dir[k].slot - r->slot_base); next_slot <= s_rel && next_slot < r->idx.size(); ++next_slot)
+            r->slot_first[next_slot] = o;
         if (e == k + 1) {
             const RunEnt& d = dir[k];
             const uint32_t len = d.len & 0x7FFFFFFFu;
@@ -703,6 +708,7 @@ static int ensure_ordered(pm_result* r) {
         }
         k = e;
     }
+    for (; next_slot <= r->idx.size(); ++next_slot) r->slot_first[next_slot] = o;
     r->n_out = o;
     { int rc = take_hit_buffer(std::max<uint64_t>(std::max<uint64_t>(o, 2 * (uint64_t)np), 1), &r->d_ord); if (rc) return done(rc); }
     // the plan travels in the (unused) directory part of the destination buffer
@@ -768,6 +774,33 @@ extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64
     }
     *hits = (const pm_hit_t*)r->host.p; *n = r->n_out;
     return PM_OK;
+}
+// The ordered records of ONE index of the search (slot = its position in the idx array), read back on their own into a
+// pooled pinned buffer: the host half of a stage works batch by batch, and pinning memory for a whole search's records
+// (hundreds of MB at a million reads) costs more than copying them.
+struct pm_slice { PinBuf buf; };
+extern "C" int pm_result_slot_hits(pm_result_t* r, uint32_t slot, const pm_hit_t** hits, uint64_t* n, pm_slice_t** slice) {
+    NEED_DEV();
+    if (!r || !hits || !n || !slice) return fail(PM_EINVAL, "bad argument");
+    RESULT_READY(r);
+    if (slot >= r->idx.size()) return fail(PM_EINVAL, "slot %u of a search over %zu indexes", slot, r->idx.size());
+    { int rc = ensure_ordered(r); if (rc) return rc; }
+    uint64_t first = 0, count = 0;
+    if (r->n_out) { first = r->slot_first[slot]; count = r->slot_first[slot + 1] - first; }
+    pm_slice* sl = new pm_slice{PinBuf{nullptr, 0}};
+    if (count) {
+        { int rc = take_pinned((size_t)count * sizeof(pm_hit_t), &sl->buf); if (rc) { delete sl; return rc; } }
+        hipError_t e = hipMemcpyAsync(sl->buf.p, r->d_ord.p + first, count * sizeof(pm_hit_t), hipMemcpyDeviceToHost, g_ctx.d2h_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.d2h_stream);
+        if (e != hipSuccess) { give_pinned(sl->buf); delete sl; return fail(PM_EHIP, "reading back slot %u: %s", slot, hipGetErrorString(e)); }
+    }
+    *hits = (const pm_hit_t*)sl->buf.p; *n = count; *slice = sl;
+    return PM_OK;
+}
+extern "C" void pm_slice_free(pm_slice_t* sl) {
+    if (!sl) return;
+    give_pinned(sl->buf);
+    delete sl;
 }
 extern "C" void pm_result_free(pm_result_t* r) {
     if (!r) return;

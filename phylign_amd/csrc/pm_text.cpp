@@ -437,6 +437,7 @@ struct pm_merge {
     // the table is 2^region_bits regions (top bits of the hash), probing wraps inside a region: regions are filled by
     // different threads, each in record order (so "the last one wins" holds)
     uint32_t region_bits = 0;
+    bool dup_names = false, tab_names = false;                // a repeated query name / a TAB inside one: pm_merge_add stays on one thread
     uint32_t slot0(uint64_t h, uint32_t* base, uint32_t* rmask) const {
         const uint32_t rsize = (mask + 1u) >> region_bits;
         *rmask = rsize - 1u;
@@ -553,9 +554,15 @@ extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t*
         m->region_bits = 0;
         std::fill(m->table.begin(), m->table.end(), pm_merge::kEmpty);
     }
+    std::atomic<bool> dups(false), tabs(false);
     parallel_for(nt, [&](size_t t) {
-        for (size_t i = nq * t / nt; i < nq * (t + 1) / nt; ++i) m->canon[i] = m->lookup(m->qname_p[i], m->qname_n[i]);
+        for (size_t i = nq * t / nt; i < nq * (t + 1) / nt; ++i) {
+            m->canon[i] = m->lookup(m->qname_p[i], m->qname_n[i]);
+            if (m->canon[i] != i) dups.store(true, std::memory_order_relaxed);
+            if (memchr(m->qname_p[i], '\t', m->qname_n[i])) tabs.store(true, std::memory_order_relaxed);
+        }
     });
+    m->dup_names = dups.load(); m->tab_names = tabs.load();
     *out = m;
     return PM_OK;
 }
@@ -613,41 +620,65 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
             mb.ref_rank[order[i]] = r;
         }
     }
-    size_t p = 0;
-    while (p < n_mine) {
-        size_t e = p;
-        const uint32_t qi = mine[p].query;
-        while (e < n_mine && mine[e].query == qi) ++e;
-        while (p < e && mine[p].doc == PM_DOC_COUNT) ++p;            // count records carry no match
-        if (p == e) continue;
-        // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
-        // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
-        // (a name holds no TAB in practice: then that text is the query's own name and the lookup is canon[])
-        uint32_t target = m->canon[qi];
-        if (const void* tab = memchr(m->qname_p[qi], '\t', m->qname_n[qi])) {
-            const size_t kn = (size_t)((const char*)tab - m->qname_p[qi]);
-            target = m->lookup(m->qname_p[qi], kn);
-            if (target == pm_merge::kEmpty)
-                return fail(PM_EINVAL, "query '%.*s' of batch %s is not in the query file", (int)kn, m->qname_p[qi], batch);
-        }
-        std::vector<MergeItem>& v = m->items[target];
-        const size_t before = v.size();
-        uint32_t nth = 0;
-        for (size_t i = p; i < e; ++i) {
-            if (nb_best >= 0) {                          // per-batch post-filter, same rule as pm_format_hits
-                const int64_t rank = (int64_t)(i - p) + 1;
-                if (rank == nb_best) nth = mine[i].score;
-                if (rank > nb_best && mine[i].score != nth) continue;
+    // records [pa, pb) (whole queries): distinct queries have distinct targets unless the query file repeats a name, so
+    // ranges of queries can be merged on several threads; the first error in record order is the one reported
+    auto add_range = [&](size_t pa, size_t pb, std::string& err) -> int {
+        char msg[512];
+        size_t p = pa;
+        while (p < pb) {
+            size_t e = p;
+            const uint32_t qi = mine[p].query;
+            while (e < pb && mine[e].query == qi) ++e;
+            while (p < e && mine[p].doc == PM_DOC_COUNT) ++p;            // count records carry no match
+            if (p == e) continue;
+            // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
+            // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
+            // (a name holds no TAB in practice: then that text is the query's own name and the lookup is canon[])
+            uint32_t target = m->canon[qi];
+            if (const void* tab = memchr(m->qname_p[qi], '\t', m->qname_n[qi])) {
+                const size_t kn = (size_t)((const char*)tab - m->qname_p[qi]);
+                target = m->lookup(m->qname_p[qi], kn);
+                if (target == pm_merge::kEmpty) {
+                    snprintf(msg, sizeof msg, "query '%.*s' of batch %s is not in the query file", (int)kn, m->qname_p[qi], batch);
+                    err = msg;
+                    return PM_EINVAL;
+                }
             }
-            if (bad_name[mine[i].doc]) {
-                const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
-                return fail(PM_EINVAL, "document name '%s' must hold exactly one '_' (scripts/filter_queries.py:64)", nm);
+            std::vector<MergeItem>& v = m->items[target];
+            const size_t before = v.size();
+            uint32_t nth = 0;
+            for (size_t i = p; i < e; ++i) {
+                if (nb_best >= 0) {                          // per-batch post-filter, same rule as pm_format_hits
+                    const int64_t rank = (int64_t)(i - p) + 1;
+                    if (rank == nb_best) nth = mine[i].score;
+                    if (rank > nb_best && mine[i].score != nth) continue;
+                }
+                if (bad_name[mine[i].doc]) {
+                    const char* nm = ix->names_blob.data() + ix->name_off[mine[i].doc];
+                    snprintf(msg, sizeof msg, "document name '%s' must hold exactly one '_' (scripts/filter_queries.py:64)", nm);
+                    err = msg;
+                    return PM_EINVAL;
+                }
+                if (mine[i].score >= m->floor_[target]) v.push_back({mine[i].score, bid, mine[i].doc});
             }
-            if (mine[i].score >= m->floor_[target]) v.push_back({mine[i].score, bid, mine[i].doc});
+            { int rc = merge_settle(m, target, before, true); if (rc) { err = pm_last_error(); return rc; } }
+            p = e;
         }
-        { int rc = merge_settle(m, target, before, true); if (rc) return rc; }
-        p = e;
+        return PM_OK;
+    };
+    size_t nt = m->dup_names || m->tab_names ? 1 : std::min<size_t>(parallel_width(), n_mine / 16384);
+    if (nt < 1) nt = 1;
+    std::vector<size_t> cut(nt + 1, n_mine);
+    cut[0] = 0;
+    for (size_t t = 1; t < nt; ++t) {                    // cuts at query boundaries
+        size_t c = std::max(cut[t - 1], n_mine * t / nt);
+        while (c < n_mine && c > 0 && mine[c].query == mine[c - 1].query) ++c;
+        cut[t] = c;
     }
+    std::vector<int> rcs(nt, PM_OK);
+    std::vector<std::string> errs(nt);
+    parallel_for(nt, [&](size_t t) { rcs[t] = add_range(cut[t], cut[t + 1], errs[t]); });
+    for (size_t t = 0; t < nt; ++t) if (rcs[t] != PM_OK) return fail(rcs[t], "%s", errs[t].c_str());
     return PM_OK;
 }
 

@@ -253,15 +253,19 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
         res.wait()
         st = res.stats
         t1 = time.perf_counter()
-        hits = res.hits(copy=False)                     # ordered (slot, query, ...): view of pinned memory, lives as long as `res`
-        t2 = time.perf_counter()
-        cut = np.searchsorted(hits["slot"], np.arange(len(group) + 1, dtype=np.uint32))
-        add_time("gpu_wait_s", t1 - t0); add_time("d2h_s", t2 - t1); add_time("match_only_s", st.ms_total * 1e-3)
+        add_time("gpu_wait_s", t1 - t0); add_time("match_only_s", st.ms_total * 1e-3)
 
         def one(i):
             pos, ix, _held = group[i]
             b = batches[pos]
-            part = hits[cut[i]:cut[i + 1]]
+            t_a = time.perf_counter()
+            # the batch's records (ordered by query, best first) come back on their own, into a pooled pinned buffer:
+            # the first worker also pays the ordering of the runs on the device
+            with res.slot_hits(i) as sl:
+                add_time("d2h_s", time.perf_counter() - t_a)
+                return one_batch(i, b, ix, sl.hits)
+
+        def one_batch(i, b, ix, part):
             path = os.path.join(out_dir, f"{b}____{qfile}.gz")
             ta = time.perf_counter()
             if keep_texts is None:

@@ -107,6 +107,14 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
             r1 = pm.search_async(ixs, q, thr, slot_base=base, nb_best_hits=n)
             r2 = pm.search_async(ixs, q, thr, slot_base=base)
             got[(bound, wq, split, single)] = (r1.hits(), r2.hits())
+            if (bound, wq, split, single) == (1, 0, 0, 0):
+                # the records of one index read back on their own (what the stage's workers do) = that slot's slice
+                for r, h in ((r1, got[(1, 0, 0, 0)][0]), (r2, got[(1, 0, 0, 0)][1])):
+                    for s_ in range(len(ixs)):
+                        with r.slot_hits(s_) as sl:
+                            assert np.array_equal(sl.hits, h[h["slot"] == base + s_]), s_
+                with pytest.raises(pm.PMError):
+                    r1.slot_hits(len(ixs))
     finally:
         pm.set_option("threshold_bound", 1)
         pm.set_option("wide_query", 0)

@@ -182,6 +182,11 @@ void pm_index_free(pm_index_t* idx);
  * are dropped.  Fails with PM_EQUERY on a sequence shorter than term_size or
  * holding a byte outside ACGT. */
 int  pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out);
+/* where a prepared query file is cut into pieces of max_records records each (offsets of record starts: the lines that
+ * begin with '>' or ';'); *cuts (pm_free) holds *n_cuts ascending offsets, none when the file has no more records than
+ * that.  For query files with more reads than fit HBM at once (a 01_queries_merged file is one per query set:
+ * Snakefile:336-352). */
+int  pm_fasta_record_cuts(const char* fasta, size_t len, uint64_t max_records, uint64_t** cuts, uint64_t* n_cuts);
 /* normalise != 0: `buf` is an unprocessed query file (FASTA or FASTQ, multi-line, lower case, IUPAC
  * codes, comments) and the parser applies rules fix_query + concatenate_queries itself
  * (Snakefile:314-352: `seqtk seq -A -U -C | awk gsub(/[^ACGT]/, "A")`, kseq record rules): names cut
@@ -320,6 +325,9 @@ int  pm_merge_emit(const pm_merge_t* m, char** text, size_t* len);
 /* the same text written to `path` (via "<path>.tmp" + rename), built and written on several threads;
  * *bytes (optional) = size of the file */
 int  pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes);
+/* the same for a query file searched in chunks (one merge per chunk, in file order): piece 1 = first (creates
+ * "<path>.tmp"), 2 = middle (appends), 3 = last (appends and renames to `path`), 0 = the whole file; *bytes = this piece */
+int  pm_merge_emit_file_piece(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes);
 void pm_merge_free(pm_merge_t* m);
 
 #ifdef __cplusplus

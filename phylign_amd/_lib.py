@@ -76,7 +76,8 @@ SYMBOLS = [
     ("pm_index_read_row", C.c_int, [_P, C.c_uint64, _P]),
     ("pm_index_free", None, [_P]),
     ("pm_queries_parse", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
-    ("pm_queries_parse_raw", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    ("pm_queries_parse_raw", C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    ("pm_fasta_record_cuts", C.c_int, [_P, C.c_size_t, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_queries_fasta", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_queries_count", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pm_queries_terms", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -109,6 +110,7 @@ SYMBOLS = [
     ("pm_merge_export", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_emit_file", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
+    ("pm_merge_emit_file_piece", C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]),
     ("pm_merge_free", None, [_P]),
     ("pm_query_text", C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_double, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t)]),
 ]
@@ -283,6 +285,35 @@ class Index:
             pass
 
 
+def _buffer_ptr(buf):
+    """(address, length, object to keep alive) of a bytes-like object, without copying it"""
+    if isinstance(buf, bytes):
+        return C.cast(C.c_char_p(buf), _P).value if buf else None, len(buf), buf
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    return (arr.ctypes.data if arr.size else None), arr.size, arr
+
+
+def fasta_record_cuts(fasta, max_records):
+    """offsets at which a prepared query file is cut into pieces of max_records records (see the header)"""
+    ptr, n, _keep = _buffer_ptr(fasta)
+    p, k = _P(), C.c_uint64()
+    _chk(load().pm_fasta_record_cuts(ptr, n, max_records, C.byref(p), C.byref(k)))
+    if not k.value:
+        return []
+    out = list((C.c_uint64 * k.value).from_address(p.value))
+    load().pm_free(p)
+    return out
+
+
+def emit_merges_to(merges, path) -> int:
+    """the 04_filter FASTA of a query file searched in chunks: the merges' records in chunk (= file) order"""
+    total = 0
+    for i, m in enumerate(merges):
+        piece = 0 if len(merges) == 1 else (1 if i == 0 else (3 if i == len(merges) - 1 else 2))
+        total += m.emit_to(path, piece)
+    return total
+
+
 class Queries:
     """A query FASTA parsed with the cobs CLI's record rules, resident in HBM."""
 
@@ -290,7 +321,8 @@ class Queries:
         """normalise: `fasta` is an unprocessed FASTA/FASTQ; rules fix_query + concatenate_queries
         (Snakefile:314-352) are applied by the native parser"""
         h = _P()
-        _chk(load().pm_queries_parse_raw(fasta, len(fasta), term_size, int(bool(normalise)), C.byref(h)))
+        ptr, n, _keep = _buffer_ptr(fasta)                 # bytes or any buffer (a memoryview slice of a big file: no copy)
+        _chk(load().pm_queries_parse_raw(ptr, n, term_size, int(bool(normalise)), C.byref(h)))
         self._h = h
 
     def fasta(self) -> bytes:
@@ -473,10 +505,11 @@ class Merge:
         load().pm_free(p)
         return out
 
-    def emit_to(self, path) -> int:
-        """writes the 04_filter FASTA to `path` (atomically); returns its size"""
+    def emit_to(self, path, piece=0) -> int:
+        """writes the 04_filter FASTA to `path` (atomically); returns its size.  piece: 0 = the whole file; for a query
+        file searched in chunks 1 = first merge, 2 = a middle one, 3 = the last (the file appears with it)"""
         n = C.c_uint64()
-        _chk(load().pm_merge_emit_file(self._h, os.fsencode(path), C.byref(n)))
+        _chk(load().pm_merge_emit_file_piece(self._h, os.fsencode(path), piece, C.byref(n)))
         return n.value
 
     def emit(self) -> bytes:

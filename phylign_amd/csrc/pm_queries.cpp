@@ -96,6 +96,52 @@ static int parse_cobs_range(pm_queries* q, const char* fasta, size_t begin, size
     return rc;
 }
 
+// Offsets at which a prepared query file (records start with '>' or ';' at a line start) is cut into pieces of
+// `max_records` records: what match_stage --query-chunk needs for a file of more reads than fit HBM at once.  Record
+// starts are counted on several threads, then the cuts are located inside the pieces that hold them.
+extern "C" int pm_fasta_record_cuts(const char* fasta, size_t len, uint64_t max_records, uint64_t** cuts, uint64_t* n_cuts) {
+    if ((!fasta && len) || !cuts || !n_cuts) return fail(PM_EINVAL, "bad argument");
+    *cuts = nullptr; *n_cuts = 0;
+    if (max_records == 0 || len == 0) return PM_OK;
+    const size_t np = std::max<size_t>(1, (len + (8u << 20) - 1) / (8u << 20));
+    // record starts in [a, b): counted; with `first` (the 1-based ordinal of the piece's first record) the starts whose
+    // ordinal is 1 modulo max_records (the first record of a later piece) are noted
+    auto walk = [&](size_t a, size_t b, uint64_t first, std::vector<uint64_t>* note) -> uint64_t {
+        uint64_t n = 0;
+        auto seen = [&](size_t at) {
+            if (note && first + n > 1 && (first + n - 1) % max_records == 0) note->push_back((uint64_t)at);
+            ++n;
+        };
+        size_t p = a;
+        if (p == 0) {
+            if (fasta[0] == '>' || fasta[0] == ';') seen(0);
+            p = 1;
+        }
+        while (p < b) {                                          // a record starts at p when a newline stands at p - 1
+            const char* nl = (const char*)memchr(fasta + p - 1, '\n', b - p);
+            if (!nl) break;
+            p = (size_t)(nl - fasta) + 1;
+            if (fasta[p] == '>' || fasta[p] == ';') seen(p);
+            ++p;
+        }
+        return n;
+    };
+    std::vector<uint64_t> cnt(np, 0);
+    parallel_for(np, [&](size_t t) { cnt[t] = walk(len * t / np, len * (t + 1) / np, 0, nullptr); });
+    std::vector<uint64_t> first(np, 1);
+    for (size_t t = 1; t < np; ++t) first[t] = first[t - 1] + cnt[t - 1];
+    std::vector<std::vector<uint64_t>> found(np);
+    parallel_for(np, [&](size_t t) { (void)walk(len * t / np, len * (t + 1) / np, first[t], &found[t]); });
+    std::vector<uint64_t> out;
+    for (auto& f : found) out.insert(out.end(), f.begin(), f.end());
+    if (out.empty()) return PM_OK;
+    uint64_t* buf = (uint64_t*)malloc(out.size() * sizeof(uint64_t));
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    memcpy(buf, out.data(), out.size() * sizeof(uint64_t));
+    *cuts = buf; *n_cuts = out.size();
+    return PM_OK;
+}
+
 extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
     if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
     pm_queries* q = new pm_queries();

@@ -881,14 +881,31 @@ extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
 // The same text written to `path` (through "<path>.tmp" + rename: never a partial file that looks
 // complete), the pieces written in parallel at their offsets: the 04_filter FASTA of a million reads
 // is hundreds of MB that need not pass through the caller.
+static int merge_emit_file_impl(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes);
 extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes) {
+    return merge_emit_file_impl(m, path, 0, bytes);
+}
+// The FASTA of a query file that was searched in chunks (one merge per chunk, in file order): piece 1 = first (creates
+// "<path>.tmp"), 2 = a middle one (appends), 3 = the last (appends, then renames to `path`); 0 = the whole file.
+extern "C" int pm_merge_emit_file_piece(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes) {
+    if (piece < 0 || piece > 3) return fail(PM_EINVAL, "piece must be 0 (whole), 1 (first), 2 (middle) or 3 (last)");
+    return merge_emit_file_impl(m, path, piece, bytes);
+}
+static int merge_emit_file_impl(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes) {
     if (!m || !path) return fail(PM_EINVAL, "bad argument");
     EmitPlan pl;
     merge_emit_plan(m, pl);
     const size_t nb = pl.first.size() - 1;
     const std::string tmp = std::string(path) + ".tmp";
-    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) return fail(PM_EIO, "cannot create '%s': %s", tmp.c_str(), strerror(errno));
+    const bool append = piece == 2 || piece == 3, finish = piece == 0 || piece == 3;
+    int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
+    if (fd < 0) return fail(PM_EIO, "cannot %s '%s': %s", append ? "append to" : "create", tmp.c_str(), strerror(errno));
+    uint64_t base = 0;
+    if (append) {
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { const int e0 = errno; close(fd); return fail(PM_EIO, "stat '%s': %s", tmp.c_str(), strerror(e0)); }
+        base = (uint64_t)sb.st_size;
+    }
     // a worker formats runs of blocks of ~4 MB into one pooled scratch buffer and writes each at its offset
     const size_t nt = std::max<size_t>(1, std::min<size_t>(parallel_width(), nb / 4));
     std::vector<int> errs(nt, 0);
@@ -903,7 +920,7 @@ extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_
             if (!scratch.p) { errs[t] = ENOMEM; break; }
             char* w = scratch.p;
             for (size_t k = b; k < e; ++k) w = merge_emit_block(m, pl, k, w);
-            const char* p = scratch.p; size_t left = need; uint64_t o = pl.off[b];
+            const char* p = scratch.p; size_t left = need; uint64_t o = base + pl.off[b];
             while (left) {
                 ssize_t wr = pwrite(fd, p, left, (off_t)o);
                 if (wr < 0) { if (errno == EINTR) continue; errs[t] = errno; break; }
@@ -917,7 +934,7 @@ extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_
     for (int x : errs) if (x) e = x;
     if (close(fd) != 0 && !e) e = errno;
     if (e) { (void)unlink(tmp.c_str()); return fail(PM_EIO, "writing '%s': %s", tmp.c_str(), strerror(e)); }
-    if (rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
+    if (finish && rename(tmp.c_str(), path) != 0) return fail(PM_EIO, "rename to '%s': %s", path, strerror(errno));
     if (bytes) *bytes = pl.off.back();
     return PM_OK;
 }

@@ -161,20 +161,16 @@ class ResidentSource:
 
 def split_prepared_fasta(fasta, max_records):
     """cuts a prepared query file (records start with '>' or ';' at a line start) into pieces of at most max_records
-    records; returns the list of byte strings (one piece when max_records <= 0)"""
+    records; returns the list of pieces -- views of `fasta`, nothing is copied (one piece when max_records <= 0)"""
     if max_records <= 0:
         return [fasta]
-    arr = np.frombuffer(fasta, dtype=np.uint8)
-    nl = np.flatnonzero(arr[:-1] == 10)
-    nxt = arr[nl + 1]
-    starts = nl[(nxt == 62) | (nxt == 59)] + 1                    # '>' or ';' right after a newline
-    if len(arr) and arr[0] in (62, 59):
-        starts = np.concatenate(([0], starts))
-    if len(starts) <= max_records:
+    from . import _lib as pm
+    cuts = pm.fasta_record_cuts(fasta, max_records)
+    if not cuts:
         return [fasta]
-    cuts = [int(starts[i]) for i in range(max_records, len(starts), max_records)]
+    view = memoryview(fasta)
     bounds = [0] + cuts + [len(fasta)]
-    return [fasta[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)]
+    return [view[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)]
 
 
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
@@ -485,18 +481,7 @@ def main(argv=None):
                                 nix.free()
         if rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
-            if len(merges) == 1:
-                report["filter_fasta_bytes"] = merges[0].emit_to(args.filter_out)
-            else:
-                tmp = args.filter_out + ".tmp"
-                total = 0
-                with open(tmp, "wb") as f:
-                    for merge in merges:                              # chunks are in file order: so are the records
-                        piece = merge.emit()
-                        f.write(piece)
-                        total += len(piece)
-                os.replace(tmp, args.filter_out)
-                report["filter_fasta_bytes"] = total
+            report["filter_fasta_bytes"] = pm.emit_merges_to(merges, args.filter_out)   # chunks are in file order: so are the records
     report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
     if world > 1:
         dist.barrier()

@@ -604,6 +604,31 @@ def test_native_merge_name_table_at_scale_keeps_dict_semantics(tmp_path):
     assert (tmp_path / "f.fa").read_bytes().decode() == out.getvalue() and n == len(out.getvalue())
 
 
+def test_merge_fasta_of_a_chunked_query_file_is_written_piece_by_piece(tmp_path):
+    """one merge per query chunk (match_stage --query-chunk): pm_merge_emit_file_piece appends the chunks' records in file
+    order; the file appears with the last piece and equals the concatenation of the merges' texts"""
+    from phylign_amd import _lib as pm
+    rng = np.random.default_rng(71)
+    fa = [b"".join(b">c%dq%d x\nACGTACGTACGTACGTACGTACGTACGTACGTA\n" % (c, i) for i in range(20000)) for c in range(3)]
+    qs = [pm.Queries(f) for f in fa]
+    ix = pm.Index.from_names([f"{i:03x}_R{i}" for i in range(30)])
+    ms = []
+    for q in qs:
+        m = pm.Merge(q, 5)
+        rec = np.zeros(3000, dtype=pm.HIT_DTYPE)
+        rec["query"] = np.sort(rng.integers(0, 20000, 3000)); rec["doc"] = rng.integers(0, 30, 3000); rec["score"] = rng.integers(1, 9, 3000)
+        m.add("b", ix, pm.sort_hits(rec), slot=0)
+        ms.append(m)
+    p = tmp_path / "f.fa"
+    assert ms[0].emit_to(str(p), 1) and not p.exists() and (tmp_path / "f.fa.tmp").exists()
+    n = pm.emit_merges_to(ms, str(p))
+    want = b"".join(m.emit() for m in ms)
+    assert p.read_bytes() == want and n == len(want) and not (tmp_path / "f.fa.tmp").exists()
+    assert pm.emit_merges_to(ms[:1], str(p)) == len(ms[0].emit()) and p.read_bytes() == ms[0].emit()
+    with pytest.raises(pm.PMError):
+        ms[0].emit_to(str(p), 9)
+
+
 def test_header_reader_survives_corrupted_input(oracle):
     """classic / compact header bytes with random flips, truncations and insertions: the product
     reader either reports PM_EFORMAT / PM_EIO-style errors or returns a consistent handle -- it never
@@ -1036,6 +1061,16 @@ def test_match_file_pieces_and_query_file_splitting(tmp_path):
         assert b"".join(pieces) == fasta
         assert all(p[:1] in (b">", b";") for p in pieces)
         assert len(pieces) == (1 if size <= 0 or size >= n else -(-n // size))
+    # a file of several counting pieces (8 MB each, counted on several threads): the cuts are those of a plain scan
+    big = b"".join((b";s%d\n" % i if i % 1013 == 0 else b">read%07d some comment\n" % i) + b"ACGT" * (9 + i % 5) + b"\n" for i in range(450000))
+    arr = np.frombuffer(big, dtype=np.uint8)
+    nl = np.flatnonzero(arr[:-1] == 10)
+    starts = np.concatenate(([0], nl[(arr[nl + 1] == 62) | (arr[nl + 1] == 59)] + 1))
+    assert len(big) > 3 * (8 << 20) and len(starts) == 450000
+    for size in (1, 7, 4096, 100000, 449999, 450000):
+        got = pm.fasta_record_cuts(big, size)
+        assert got == [int(x) for x in starts[size::size]], size
+    assert pm.fasta_record_cuts(b"", 5) == [] and pm.fasta_record_cuts(b"ACGT\n>a\nAC\n>b\nAC\n", 1) == [11]
     ix = pm.Index.from_names([f"{i:05x}_R{i}" for i in range(40)])
     rng = np.random.default_rng(4)
     whole_q = pm.Queries(fasta, term_size=31)

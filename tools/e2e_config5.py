@@ -85,15 +85,7 @@ def main():
                                           args.nb_best_hits, want_merge=True, max_group=mg)
             t1 = time.perf_counter()
             os.makedirs(os.path.join(args.out, "04_filter"), exist_ok=True)
-            if len(merges) == 1:
-                fasta_bytes = merges[0].emit_to(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
-            else:
-                fasta_bytes = 0
-                with open(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"), "wb") as f:
-                    for m_ in merges:
-                        piece = m_.emit()
-                        f.write(piece)
-                        fasta_bytes += len(piece)
+            fasta_bytes = pm.emit_merges_to(merges, os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
             t2 = time.perf_counter()
             for m_ in merges:
                 m_.free()

@@ -285,8 +285,8 @@ int  pm_format_hits_gz_piece(const pm_index_t* idx, const pm_queries_t* q,
                              const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits,
                              const char* path, int level, int piece, uint64_t* text_bytes, uint64_t* gz_bytes);
 /* `gzip --fast` of a result text as the stage writes it (level 1 above): the text is cut at line boundaries into ~1 MiB
- * pieces, each becomes one gzip member (fixed-Huffman deflate; matches are found through the line structure of cobs /
- * post-filter output: the last line with the same reference name, the previous "*" line), built on several threads.
+ * pieces, each becomes one gzip member (one deflate block with Huffman codes built from the member's counts; matches
+ * are found through the line structure of cobs / post-filter output: the last line with the same reference name, the previous "*" line), built on several threads.
  * Any byte string is accepted; `gzip -dc` / xopen / Python's gzip decode the result to `text` (Snakefile:427, :468, :483
  * only ever pipe into `gzip --fast`; scripts/filter_queries.py:46 only ever inflates).  *gz is freed with pm_free(). */
 int  pm_gzip_fast(const char* text, size_t len, char** gz, size_t* gz_len);

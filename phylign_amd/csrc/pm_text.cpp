@@ -252,10 +252,10 @@ static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit
     return PM_OK;
 }
 
-// pieces of ~1 MiB that end on a line boundary (64 MiB at most, whatever the lines are): the units of the parallel deflate
+// pieces of ~1 MiB that end on a line boundary (4 MiB at most, whatever the lines are): the units of the parallel deflate
 struct Chunk { const char* p; size_t n; };
 static void cut_chunks(const char* p, size_t n, std::vector<Chunk>& chunks) {
-    constexpr size_t kChunk = 1u << 20, kMax = 64u << 20;
+    constexpr size_t kChunk = 1u << 20, kMax = 4u << 20;
     size_t o = 0;
     while (o < n) {
         size_t e = std::min(n, o + kChunk);

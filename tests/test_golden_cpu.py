@@ -533,8 +533,8 @@ def test_parallel_gzip_members_decode_like_gzip_fast(tmp_path):
 
 
 def test_fast_gzip_encoder_streams_decode_to_their_input(tmp_path):
-    """pm_gzip_fast (the level-1 encoder of the 03_match writer: fixed-Huffman deflate with line-structured
-    matches): every stream decodes, with Python's gzip and the gzip CLI, to exactly the bytes that went in --
+    """pm_gzip_fast (the level-1 encoder of the 03_match writer: deflate with line-structured matches and Huffman
+    codes built per member): every stream decodes, with Python's gzip and the gzip CLI, to exactly the bytes that went in --
     result-shaped text, binary noise (9-bit literals), very long lines (matches of 258, distances up to and
     beyond the 32 KiB window), repeated names near and far, no trailing newline, more than one member"""
     import gzip
@@ -544,6 +544,14 @@ def test_fast_gzip_encoder_streams_decode_to_their_input(tmp_path):
     cases = [b"", b"\n", b"a", b"abc\n" * 3, b"\xff\x90\x8f" * 1000, bytes(rng.integers(0, 256, 100000, dtype=np.uint8)),
              b"x" * 100000 + b"\n" + b"x" * 100000, (b"y" * 40000 + b"\n") * 5, (b"z" * 32767 + b"\n") * 3, (b"w" * 32768 + b"\n") * 3,
              b"_SAM1\t5\n" * 9000, b"".join(b"*read%d\t0\n" % i for i in range(250000))]
+    # literal counts like Fibonacci numbers: an unlimited Huffman code would be 27 bits deep (the 15-bit limit and its
+    # repair); every byte value equally often; one value only; two values
+    fib = [1, 1]
+    while len(fib) < 28:
+        fib.append(fib[-1] + fib[-2])
+    skew = np.concatenate([np.full(f, 11 + i, dtype=np.uint8) for i, f in enumerate(fib)])
+    cases += [bytes(rng.permutation(skew)), bytes(rng.permutation(np.tile(np.arange(256, dtype=np.uint8), 300))), b"\x00" * 70000,
+              bytes(rng.integers(65, 67, 50000, dtype=np.uint8))]
     for _ in range(150):
         names = [b"_SAM%07d" % rng.integers(0, 10**7) for _ in range(int(rng.integers(1, 60)))]
         lines = []

@@ -181,16 +181,21 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
             total_seq += part[t].seqs.size(); total_rec += part[t].headers.size();
         }
         if (rc == PM_OK) {
-            q->seqs.reserve(total_seq);
-            q->headers.reserve(total_rec); q->headerless.reserve(total_rec); q->n_terms.reserve(total_rec); q->seq_off.reserve(total_rec + 1);
-            for (size_t t = 0; t < n; ++t) {
-                const uint64_t base = q->seqs.size();
-                for (uint64_t o : part[t].seq_off) q->seq_off.push_back(base + o);
-                q->seqs += part[t].seqs;
-                for (auto& h : part[t].headers) q->headers.push_back(std::move(h));
-                q->headerless.insert(q->headerless.end(), part[t].headerless.begin(), part[t].headerless.end());
-                q->n_terms.insert(q->n_terms.end(), part[t].n_terms.begin(), part[t].n_terms.end());
-            }
+            // the pieces' records go to their places in the whole on the threads that parsed them
+            std::vector<size_t> rec0(n + 1, 0), seq0(n + 1, 0);
+            for (size_t t = 0; t < n; ++t) { rec0[t + 1] = rec0[t] + part[t].headers.size(); seq0[t + 1] = seq0[t] + part[t].seqs.size(); }
+            q->seqs.resize(total_seq);
+            q->headers.resize(total_rec); q->headerless.resize(total_rec); q->n_terms.resize(total_rec); q->seq_off.resize(total_rec);
+            parallel_for(n, [&](size_t t) {
+                memcpy(&q->seqs[seq0[t]], part[t].seqs.data(), part[t].seqs.size());
+                for (size_t i = 0; i < part[t].headers.size(); ++i) {
+                    q->headers[rec0[t] + i] = std::move(part[t].headers[i]);
+                    q->seq_off[rec0[t] + i] = seq0[t] + part[t].seq_off[i];
+                }
+                std::copy(part[t].headerless.begin(), part[t].headerless.end(), q->headerless.begin() + (long)rec0[t]);
+                std::copy(part[t].n_terms.begin(), part[t].n_terms.end(), q->n_terms.begin() + (long)rec0[t]);
+                part[t] = pm_queries();                       // the piece's memory goes back here, not serially at the end
+            });
         }
     }
     if (rc == PM_OK) rc = finish_queries(q);

@@ -159,25 +159,38 @@ class ResidentSource:
         return self.indexes[batch]
 
 
-def split_prepared_fasta(fasta, max_records):
+def split_prepared_fasta(fasta, max_records, piece_bytes=0):
     """cuts a prepared query file (records start with '>' or ';' at a line start) into pieces of at most max_records
-    records; returns the list of pieces -- views of `fasta`, nothing is copied (one piece when max_records <= 0)"""
-    if max_records <= 0:
-        return [fasta]
+    records, and -- piece_bytes > 0 -- pieces of more than twice that many bytes further into pieces of about piece_bytes
+    (cut at record starts): the pieces are parsed one after the other while the first ones are already searched.  Returns
+    the list of pieces -- views of `fasta`, nothing is copied (one piece when there is nothing to cut)"""
     from . import _lib as pm
-    cuts = pm.fasta_record_cuts(fasta, max_records)
-    if not cuts:
+    cuts = pm.fasta_record_cuts(fasta, max_records) if max_records > 0 else []
+    bounds = [0] + cuts + [len(fasta)]
+    if piece_bytes > 0 and isinstance(fasta, (bytes, bytearray)):
+        fine = [0]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            p = a
+            while b - p > 2 * piece_bytes:
+                hits = [x for x in (fasta.find(b"\n>", p + piece_bytes, b), fasta.find(b"\n;", p + piece_bytes, b)) if x >= 0]
+                if not hits:
+                    break
+                p = min(hits) + 1
+                fine.append(p)
+            fine.append(b)
+        bounds = fine
+    if len(bounds) <= 2:
         return [fasta]
     view = memoryview(fasta)
-    bounds = [0] + cuts + [len(fasta)]
     return [view[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)]
 
 
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
               want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
-    `batches`).  `queries` is one pm.Queries or a LIST of them: the chunks, in file order, of a query file with more reads
-    than fit HBM at once -- every group of resident batches is then searched chunk after chunk (the pipeline's units are
+    `batches`).  `queries` is one pm.Queries or a LIST of them (or of Futures of them: a file that is still being parsed):
+    the chunks, in file order, of a query file with more reads than fit HBM at once, or of one cut up so that parsing and
+    searching overlap -- every group of resident batches is then searched chunk after chunk (the pipeline's units are
     (group, chunk) pairs), a batch's file grows by one piece per chunk, and there is one merge per chunk.  Returns
     (report dict, pm.Merge / list of pm.Merge / None).  keep_texts: optional dict that receives {batch: post-filtered text}
     (tests)."""
@@ -186,12 +199,35 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     os.makedirs(out_dir, exist_ok=True)
     chunks = list(queries) if isinstance(queries, (list, tuple)) else [queries]
     nc = len(chunks)
-    nq = sum(c.count()[0] for c in chunks)
-    n_terms = sum(c.count()[1] for c in chunks)
     nb = nb_best_hits
     budget = budget_bytes if budget_bytes else 0.6 * pm.device_info()["hbm_free"]
     admit = Admission(budget)
-    merges = [pm.Merge(c, keep=nb) for c in chunks] if want_merge else None
+    merges = [None] * nc if want_merge else None
+    # a chunk may arrive as a Future of its pm.Queries (the file is still being parsed): chunks are made ready in order --
+    # parsed, and their merge state created -- by one thread that runs ahead of the searches
+    prepared, prep_err = [threading.Event() for _ in range(nc)], []
+
+    def prepare_all():
+        for ci in range(nc):
+            try:
+                if hasattr(chunks[ci], "result"):
+                    chunks[ci] = chunks[ci].result()
+                if want_merge:
+                    merges[ci] = pm.Merge(chunks[ci], keep=nb)
+            except BaseException as e:                   # noqa: BLE001 -- handed to the thread that asks for the chunk
+                prep_err.append(e)
+            prepared[ci].set()
+            if prep_err:
+                for ev in prepared[ci:]:
+                    ev.set()
+                return
+
+    def chunk(ci):
+        prepared[ci].wait()
+        if prep_err:
+            raise prep_err[0]
+        return chunks[ci]
+    threading.Thread(target=prepare_all, daemon=True).start()
     ready, ready_cv, failed = [], threading.Condition(), []
     acc = {"load_s": 0.0, "format_s": 0.0, "gzip_s": 0.0, "merge_s": 0.0, "match_only_s": 0.0, "gpu_wait_s": 0.0,
            "d2h_s": 0.0}
@@ -243,7 +279,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
 
     def finish(group, ci, res, t_queued):
         """host half of a (group, chunk) unit: runs while the GPU scans the next one"""
-        qc = chunks[ci]
+        qc = chunk(ci)
         piece = 0 if nc == 1 else (1 if ci == 0 else (3 if ci == nc - 1 else 2))
         t0 = time.perf_counter()
         res.wait()
@@ -326,7 +362,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
                 if backlog:
                     group, ci = backlog.pop(0)
                     tq = time.perf_counter()
-                    cur = (group, ci, pm.search_async([ix for _, ix, _ in group], chunks[ci], threshold, nb_best_hits=max(nb, 0)), tq)
+                    cur = (group, ci, pm.search_async([ix for _, ix, _ in group], chunk(ci), threshold, nb_best_hits=max(nb, 0)), tq)
                 if pending:
                     finish(*pending)
                 pending = cur
@@ -337,6 +373,8 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             raise
     workers.shutdown()
     deflaters.shutdown()
+    nq = sum(chunk(ci).count()[0] for ci in range(nc))
+    n_terms = sum(chunk(ci).count()[1] for ci in range(nc))
     report = {"batches": len(mine), "queries": nq, "kmers": n_terms, "query_chunks": nc, "groups": len(group_rows),
               "scan_launches": sum(g["scan_launches"] for g in group_rows),
               "match_only_s": round(acc["match_only_s"], 4), "gpu_wait_s": round(acc["gpu_wait_s"], 4),
@@ -375,6 +413,9 @@ def main(argv=None):
                     help="concurrent xz decoders per rank (0 = the CPUs the job may use minus 4, at least 4, at most 16: one "
                          "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for)")
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
+    ap.add_argument("--query-piece-mb", type=int, default=48,
+                    help="a prepared query file of more than twice this many MB is parsed and searched in pieces of about this "
+                         "size: the first pieces are searched while the later ones are parsed (0 = off)")
     ap.add_argument("--query-chunk", type=int, default=4_000_000,
                     help="most reads searched at once (0 = the whole file): a query set lives in HBM with 8 bytes per k-mer, so a "
                          "file of tens of millions of reads is searched chunk after chunk against the resident batches")
@@ -438,12 +479,15 @@ def main(argv=None):
             prepared = None
     else:
         prepared = None
-    pieces = [fasta] if prepared is not None else split_prepared_fasta(fasta, args.query_chunk)
+    pieces = [fasta] if prepared is not None else split_prepared_fasta(fasta, args.query_chunk, args.query_piece_mb << 20)
+    parser = ThreadPoolExecutor(max_workers=1)
     if prepared is not None:
         chunk_list = [prepared]
     else:
-        chunk_list = [pm.Queries(p_, term_size=args.kmer_size) for p_ in pieces]   # checked against every batch's header
-    del pieces, fasta
+        # parsed one after the other by a thread of their own (the pieces are views of `fasta`): the stage searches the
+        # first pieces while the later ones are still text; term_size is checked against every batch's header
+        chunk_list = [parser.submit(pm.Queries, p_, args.kmer_size) for p_ in pieces]
+    del pieces
     budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else None
     if args.loaders <= 0:
         from .sysinfo import effective_cpus
@@ -451,6 +495,8 @@ def main(argv=None):
     report, merges = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                                want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
                                max_group=args.max_group, kmer_size=args.kmer_size)
+    parser.shutdown()
+    del fasta
     orders = report["merge_order"] if len(chunk_list) > 1 else [report["merge_order"]]
 
     # ---- 04_filter: per chunk one gather of what every rank's merge kept, rank 0 adds the parts and emits

@@ -1079,6 +1079,12 @@ def test_match_file_pieces_and_query_file_splitting(tmp_path):
         got = pm.fasta_record_cuts(big, size)
         assert got == [int(x) for x in starts[size::size]], size
     assert pm.fasta_record_cuts(b"", 5) == [] and pm.fasta_record_cuts(b"ACGT\n>a\nAC\n>b\nAC\n", 1) == [11]
+    # pieces by bytes (parsing overlaps the search of earlier pieces): cut at record starts only, nothing lost
+    for pb in (1 << 20, 3 << 20, 64 << 20):
+        pieces = split_prepared_fasta(big, 100000, pb)
+        assert b"".join(pieces) == big and all(p[:1] in (b">", b";") for p in pieces)
+        assert len(pieces) >= 5 and (pb > len(big) or max(len(p) for p in pieces) <= 2 * pb + 200)
+    assert len(split_prepared_fasta(big, 0, 1 << 20)) > 10 and split_prepared_fasta(big, 0, 0) == [big]
     ix = pm.Index.from_names([f"{i:05x}_R{i}" for i in range(40)])
     rng = np.random.default_rng(4)
     whole_q = pm.Queries(fasta, term_size=31)

@@ -222,8 +222,6 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
-    if os.environ.get("PM_OVERLAP_LAUNCHES", "0") not in ("", "0"):
-        pm.set_option("overlap_launches", 1)
     if os.environ.get("PM_SINGLE_LAUNCH", "0") not in ("", "0"):
         pm.set_option("single_launch", 1)
     if os.environ.get("PM_WIDE_QUERY"):

@@ -124,9 +124,7 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * through LDS; the threshold bound is off in that form); 1 = always, 2 = never.
  * "wide_query_split" (default 0 = automatic): in that form, how many workgroups share the steps of one query
  * (a dozen chromosome-sized queries would otherwise leave most of the chip idle); 1 = never, n = force n.
- * "single_launch" (default 0): rows of every width up to 1024 B share one launch.
- * "overlap_launches" (default 0): the mixed-width launch runs on a second stream beside the wide ones (measured: no
- * gain). */
+ * "single_launch" (default 0): rows of every width up to 1024 B share one launch. */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);

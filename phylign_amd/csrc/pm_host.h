@@ -77,7 +77,6 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;             // hash + scan kernels
-    hipStream_t aux_stream = nullptr;         // option "overlap_launches": the mixed-width launch runs beside the wide ones
     hipStream_t copy_stream = nullptr;        // index upload (H2D + re-stride)
     hipStream_t d2h_stream = nullptr;         // hit records to the host: never queues behind later kernels
     std::vector<Workspace*> ws;
@@ -168,7 +167,6 @@ extern uint32_t g_threshold_bound;
 extern uint32_t g_count_fetched;
 // pm_set_option("single_launch"): every row width (up to 1024 B) goes into the mixed-width launch
 extern uint32_t g_single_launch;
-extern uint32_t g_overlap_launches;
 // pm_set_option("wide_query"): 0 = automatic (few long queries: several lane groups share a query), 1 = always
 // where instantiated (128+ k-mers per query), 2 = never
 extern uint32_t g_wide_query;

@@ -20,7 +20,6 @@ int bind_thread() {
 uint32_t g_threshold_bound = 1;
 uint32_t g_count_fetched = 0;
 uint32_t g_single_launch = 0;
-uint32_t g_overlap_launches = 0;
 uint32_t g_wide_query = 0;
 uint32_t g_wq_split = 0;
 
@@ -107,7 +106,6 @@ extern "C" int pm_init(int device) {
     if (g_ctx.ready && g_ctx.device == device) return PM_OK;
     if (g_ctx.ready) pm_shutdown();
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&g_ctx.aux_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&g_ctx.d2h_stream, hipStreamNonBlocking));
     g_ctx.device = device;
@@ -120,7 +118,6 @@ extern "C" void pm_shutdown(void) {
     bind_thread_quiet();
     (void)hipDeviceSynchronize();
     (void)hipStreamDestroy(g_ctx.stream);
-    (void)hipStreamDestroy(g_ctx.aux_stream);
     (void)hipStreamDestroy(g_ctx.copy_stream);
     (void)hipStreamDestroy(g_ctx.d2h_stream);
     for (Workspace* w : g_ctx.ws) {
@@ -162,7 +159,6 @@ extern "C" int pm_set_option(const char* name, int64_t value) {
     if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "count_fetched") == 0) { g_count_fetched = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "single_launch") == 0) { g_single_launch = value ? 1u : 0u; return PM_OK; }
-    if (strcmp(name, "overlap_launches") == 0) { g_overlap_launches = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "wide_query") == 0) {
         if (value < 0 || value > 2) return fail(PM_EINVAL, "wide_query takes 0 (auto), 1 (always) or 2 (never)");
         g_wide_query = (uint32_t)value;

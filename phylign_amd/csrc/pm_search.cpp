@@ -322,15 +322,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     HIPCHK(hipEventRecord(r->ev1, st));
     uint64_t alg = 0;
     size_t desc_off = 0;
-    // option "overlap_launches": the mixed-width launch goes to a second stream behind the hash kernels and runs beside
-    // the wide launches; the counter read-back waits for both (the drain tail of one launch is filled by the other)
-    const bool overlap = g_overlap_launches && !g_count_fetched && groups.size() > 1;
-    bool aux_used = false;
-    if (overlap) HIPCHK(hipStreamWaitEvent(g_ctx.aux_stream, r->ev1, 0));
-    const hipStream_t main_st = st;
     for (auto& g : groups) {
-        st = (overlap && g.g == 0) ? g_ctx.aux_stream : main_st;
-        aux_used = aux_used || st != main_st;
         { int rc = ensure_hashes(q, g.canon, g.nh, &d_h); if (rc) return rc; }
         uint64_t rowsum = 0;
         for (size_t u : g.members) rowsum += units[u].ix->info.row_bytes;
@@ -416,13 +408,6 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             alg += L.algorithmic_bytes;
         }
         desc_off += g.members.size();
-    }
-    st = main_st;
-    if (aux_used) {
-        hipEvent_t ea;
-        { int rc = ws_event(ws, r->nev++, &ea); if (rc) return rc; }
-        HIPCHK(hipEventRecord(ea, g_ctx.aux_stream));
-        HIPCHK(hipStreamWaitEvent(st, ea, 0));
     }
     HIPCHK(hipEventRecord(r->ev2, st));
     // counters to the host by a one-thread kernel writing mapped pinned memory: no DMA engine on the

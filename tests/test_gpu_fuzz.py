@@ -99,12 +99,11 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
         # scan modes x wide-query form (auto, forced, off) x its split over workgroups (auto, 3 / 7 ways) x one launch
         # for all row widths
         for bound, wq, split, single in ((1, 0, 0, 0), (0, 0, 0, 0), (1, 1, 0, 0), (0, 2, 0, 0), (0, 1, 3, 0), (1, 1, 7, 1),
-                                         (0, 0, 0, 1), (1, 0, 0, 2), (0, 1, 5, 2)):
+                                         (0, 0, 0, 1)):
             pm.set_option("threshold_bound", bound)
             pm.set_option("wide_query", wq)
             pm.set_option("wide_query_split", split)
-            pm.set_option("single_launch", 1 if single == 1 else 0)
-            pm.set_option("overlap_launches", 1 if single == 2 else 0)       # 2: the mixed-width launch on a second stream
+            pm.set_option("single_launch", single)
             r1 = pm.search_async(ixs, q, thr, slot_base=base, nb_best_hits=n)
             r2 = pm.search_async(ixs, q, thr, slot_base=base)
             got[(bound, wq, split, single)] = (r1.hits(), r2.hits())
@@ -121,7 +120,6 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
         pm.set_option("wide_query", 0)
         pm.set_option("wide_query_split", 0)
         pm.set_option("single_launch", 0)
-        pm.set_option("overlap_launches", 0)
     for key in got:
         assert np.array_equal(got[key][0], got[(1, 0, 0, 0)][0]) and np.array_equal(got[key][1], got[(1, 0, 0, 0)][1]), key
     pruned, plain = got[(1, 0, 0, 0)]

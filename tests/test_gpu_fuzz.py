@@ -127,3 +127,71 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
         assert pm.format_hits(ix, q, plain, slot=base + s) == exp[s]
         if n:
             assert pm.format_hits(ix, q, pruned, slot=base + s, nb_best_hits=n).decode() == P.filter_text(exp[s].decode(), n)
+
+
+@pytest.mark.parametrize("seed", _seeds(12))
+def test_random_stage_run_files_and_fasta_identical(pm, oracle, tmp_path, seed):
+    """match_stage.run_stage on random resident batches: random grouping (--max-group), the query file whole, in record
+    chunks or in byte pieces that arrive as Futures, repeated read names now and then -- every 03_match file equals the
+    oracle's text after the post-filter, the 04_filter FASTA equals the (fixture-pinned) mirror of filter_queries.py"""
+    import gzip
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from phylign_amd import filter_queries as F
+    from phylign_amd import match_stage as MS
+    from phylign_amd import postprocess as P
+    rng = np.random.default_rng(9000 + seed)
+    nq = int(rng.integers(1, 70))
+    names_q = [f"r{i}" for i in range(nq)]
+    if nq > 4 and rng.random() < 0.4:                                 # a repeated name: dict semantics in the merge
+        for _ in range(int(rng.integers(1, 4))):
+            names_q[int(rng.integers(0, nq))] = names_q[int(rng.integers(0, nq))]
+    queries = [(names_q[i] + (" note" if i % 3 == 0 else ""), rand_seq(rng, int(rng.choice([31, 40, 100, 150, 150, 300, 900]))))
+               for i in range(nq)]
+    n_b = int(rng.integers(1, 8))
+    batches, indexes = [], {}
+    for b in range(n_b):
+        n_docs = int(rng.choice([5, 64, 100, 130, 300, 664, 1024, 2100, 4000, 8300]))
+        S = int(rng.integers(80, 2500))
+        plant = [(int(rng.integers(0, nq)), int(rng.integers(0, n_docs)), float(rng.choice([1.0, 0.9, 0.75, 0.7, 0.69, 0.4])))
+                 for _ in range(int(rng.integers(0, 80)))]
+        index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, density=float(rng.choice([0.02, 0.25, 0.5])), plant=plant)
+        name = f"g{int(rng.integers(0, 99)):02d}_s{b}__01"
+        batches.append(name)
+        indexes[name] = index
+    batches.sort()
+    n = int(rng.choice([1, 3, 100]))
+    thr = float(rng.choice([0.3, 0.7, 0.7, 1.0]))
+    src = MS.ResidentSource({b: pm.Index.load_mem(indexes[b], layout=int(rng.integers(0, 3))) for b in batches})
+    mode = int(rng.integers(0, 3))
+    parser = ThreadPoolExecutor(max_workers=1)
+    if mode == 0:
+        qarg = pm.Queries(fasta)
+    elif mode == 1:
+        qarg = [pm.Queries(p) for p in MS.split_prepared_fasta(fasta, int(rng.integers(1, max(2, nq))))]
+    else:
+        qarg = [parser.submit(pm.Queries, p) for p in MS.split_prepared_fasta(fasta, 0, int(rng.integers(64, 4000)))]
+    out_dir = tmp_path / "03_match"
+    report, merges = MS.run_stage(pm, batches, list(range(n_b)), src, qarg, "Q", str(out_dir), thr, n, want_merge=True,
+                                  max_group=int(rng.choice([0, 0, 1, 2, 3])))
+    parser.shutdown()
+    merges = merges if isinstance(merges, list) else [merges]
+    assert report["queries"] == nq
+    files = []
+    for b in batches:
+        exp = P.filter_text(oracle.query_file(indexes[b], fasta, thr).decode(), n)
+        fn = out_dir / f"{b}____Q.gz"
+        assert gzip.open(fn, "rt").read() == exp, (b, mode)
+        files.append(str(fn))
+    (tmp_path / "Q.fa").write_bytes(fasta)
+    want = io.StringIO()
+    F.filter_files(str(tmp_path / "Q.fa"), files, n, want)
+    got = pm.emit_merges_to(merges, str(tmp_path / "F.fa"))
+    if len(merges) == 1:
+        assert (tmp_path / "F.fa").read_text() == want.getvalue() and got == len(want.getvalue())
+    else:
+        # one merge per chunk: a name that repeats ACROSS chunks is one record per chunk here (DESIGN.md section 5,
+        # known deviations), so the whole-file mirror applies only when the names are unique
+        if len(set(names_q)) == nq:
+            assert (tmp_path / "F.fa").read_text() == want.getvalue()
+    assert not list(out_dir.glob("*.tmp"))

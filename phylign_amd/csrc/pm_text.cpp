@@ -696,12 +696,23 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
     std::vector<std::pair<uint32_t, size_t>> blocks;               // (target query, first record) per '*' header
     std::unordered_map<std::string, uint32_t> ref_id;
     std::vector<std::string> refs;
-    auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
-    auto parse_int = [](const char* b, const char* e, uint64_t* out) {
-        if (b < e && (*b == '+' || *b == '-')) ++b;      // int() takes a sign; the count of a header is never used
-        if (b >= e) return false;
+    // str.strip() / str.split() whitespace within ASCII: blank, TAB, CR, VT, FF and the separators 0x1c-0x1f
+    auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || (c >= 0x1c && c <= 0x1f); };
+    // Python's int(): surrounding whitespace, one sign, decimal digits with single '_' between digits; *neg: a '-' sign
+    // (the reference keeps a match only while kmers >= its floor, which starts at 0: a negative count never counts)
+    auto parse_int = [&](const char* b, const char* e, uint64_t* out, bool* neg) {
+        while (b < e && (is_ws(*b) || *b == '\n')) ++b;
+        while (e > b && (is_ws(e[-1]) || e[-1] == '\n')) --e;
+        *neg = false;
+        if (b < e && (*b == '+' || *b == '-')) { *neg = *b == '-'; ++b; }
+        if (b >= e || *b < '0' || *b > '9') return false;
         uint64_t v = 0;
-        for (; b < e; ++b) { if (*b < '0' || *b > '9') return false; v = v * 10 + (uint64_t)(*b - '0'); if (v > 0xFFFFFFFFull) return false; }
+        for (; b < e; ++b) {
+            if (*b == '_') { if (b + 1 >= e || b[1] < '0' || b[1] > '9') return false; continue; }
+            if (*b < '0' || *b > '9') return false;
+            v = v * 10 + (uint64_t)(*b - '0');
+            if (v > 0xFFFFFFFFull) return false;
+        }
         *out = v;
         return true;
     };
@@ -721,7 +732,8 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
             uint64_t n = 0;
             const char* nb = tab ? tab + 1 : e;
             const char* ne = tab ? (const char*)memchr(nb, '\t', (size_t)(e - nb)) : nullptr;
-            if (!tab || !parse_int(nb, ne ? ne : e, &n))
+            bool neg_ = false;
+            if (!tab || !parse_int(nb, ne ? ne : e, &n, &neg_))
                 return fail(PM_EINVAL, "batch %s line %zu: query header without an integer match count", batch, lineno);
             const char* qe = (const char*)memchr(b + 1, ' ', (size_t)(tab - (b + 1)));
             const size_t qn = (size_t)((qe ? qe : tab) - (b + 1));
@@ -740,7 +752,8 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
         const char* f2e = f2b;
         while (f2e < e && !is_ws(*f2e)) ++f2e;
         uint64_t km = 0;
-        if (f2b == f2e || f2e != e || !parse_int(f2b, f2e, &km))
+        bool km_neg = false;
+        if (f2b == f2e || f2e != e || !parse_int(f2b, f2e, &km, &km_neg))
             return fail(PM_EINVAL, "batch %s line %zu: a match line must be '<name> <k-mers>'", batch, lineno);
         const char* us = (const char*)memchr(b, '_', (size_t)(f1e - b));
         if (!us || memchr(us + 1, '_', (size_t)(f1e - (us + 1))))
@@ -749,6 +762,7 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
         std::string ref(us + 1, (size_t)(f1e - (us + 1)));
         auto ins = ref_id.emplace(std::move(ref), (uint32_t)refs.size());
         if (ins.second) refs.push_back(ins.first->first);
+        if (km_neg && km) continue;                       // below every floor: never kept (the line was checked like the others)
         recs.push_back({0u, ins.first->second, (uint32_t)km});
     }
     if (!have_header) return fail(PM_EINVAL, "batch %s: no '*' query header in the match text", batch);

@@ -1106,3 +1106,70 @@ def test_match_file_pieces_and_query_file_splitting(tmp_path):
     assert gzip.open(path, "rb").read() == want and not (tmp_path / "b____q.gz.tmp").exists()
     with pytest.raises(pm.PMError):
         pm.format_hits_gz(ix, whole_q, recs_all, str(path), piece=7)
+
+
+def test_native_match_text_reader_against_the_mirror_on_random_odd_input(tmp_path):
+    """pm_merge_add_text vs the Python mirror of scripts/filter_queries.py (fixture-pinned) on random 03_match-like text
+    with the oddities a text reader meets: counts written as Python's int() accepts them (' 5', '+2', '-4', '1_0'),
+    several blanks or TABs between the fields, hit lines ahead of the first header, names with no or two '_', unknown
+    queries, repeated read names.  Both fail, or both succeed with the same FASTA.  (A negative k-mer count is a valid
+    line that never counts: the reference keeps kmers >= floor, and the floor starts at 0.)"""
+    import gzip
+    import io
+    from phylign_amd import _lib as pm
+    from phylign_amd import filter_queries as F
+    rng = np.random.default_rng(91)
+    fixed = [b"*q0\t 5\nab_R1\t3\n", b"*q0\t1_0\nab_R1\t1_2\n", b"ab_R1 -4\n*q0\t+1\ncd_R2\t-0\n", b"*q0\t5 \n\x1cab_R1\x1d7\n",
+             b"*q0\t1__0\n", b"*q0\t_1\n", b"*q0\t1\nab_R1\t1_\n"]
+    agree = {"ok": 0, "err": 0}
+    for it in range(260):
+        nq = int(rng.integers(1, 10))
+        qn = [f"q{i}" for i in range(nq)]
+        if rng.random() < 0.2 and nq > 2:
+            qn[1] = qn[0]
+        fasta = "".join(f">{n}{' cm' if i % 2 else ''}\n{'ACGT' * 9}\n" for i, n in enumerate(qn)).encode()
+        (tmp_path / "q.fa").write_bytes(fasta)
+        texts = []
+        for b in range(int(rng.integers(1, 4))):
+            if it < len(fixed):
+                t = fixed[it]
+            else:
+                lines = []
+                for _ in range(int(rng.integers(0, 14))):
+                    r = rng.random()
+                    ws = str(rng.choice(["\t", " ", "  ", "\t ", "\t"]))
+                    if r < 0.35:
+                        name = str(rng.choice(qn + ["zz"] if rng.random() < 0.03 else qn))
+                        cnt = str(rng.choice(["3", "0", "+2", "-1", "x", "", "7 ", " 5", "1\t9", "1_0"])) if rng.random() < 0.15 else str(int(rng.integers(0, 9)))
+                        lines.append(f"*{name}{rng.choice(['', ' c', ' a b'])}\t{cnt}")
+                    elif r < 0.9:
+                        ref = (str(rng.choice(["ab_R1", "cd_R2", "ef_R10", "g_h_i", "noUnderscore", "_lead", "trail_"])) if rng.random() < 0.12
+                               else f"{int(rng.integers(0, 99)):02x}_R{int(rng.integers(0, 6))}")
+                        km = str(rng.choice(["12", "+3", "-4", "1.5", "", "9x", "007", "-0"])) if rng.random() < 0.12 else str(int(rng.integers(1, 40)))
+                        extra = str(rng.choice(["", " extra", "\t1"])) if rng.random() < 0.05 else ""
+                        lead = str(rng.choice(["", " ", "\t"])) if rng.random() < 0.1 else ""
+                        lines.append(f"{lead}{ref}{ws}{km}{extra}{' ' if rng.random() < 0.1 else ''}")
+                    else:
+                        lines.append(str(rng.choice(["", " ", "\t", "*"])))
+                t = ("\n".join(lines) + ("\n" if rng.random() < 0.9 else "")).encode()
+            fn = tmp_path / f"b{b}____q.gz"
+            with gzip.open(fn, "wb") as g:
+                g.write(t)
+            texts.append((f"b{b}", t, str(fn)))
+        keep = int(rng.choice([1, 2, 5]))
+        try:
+            o = io.StringIO()
+            F.filter_files(str(tmp_path / "q.fa"), [x[2] for x in texts], keep, o)
+            py = ("ok", o.getvalue())
+        except Exception:
+            py = ("err", None)
+        try:
+            m = pm.Merge(pm.Queries(fasta), keep)
+            for bn, t, _ in texts:
+                m.add_text(bn, t)
+            nat = ("ok", m.emit().decode())
+        except pm.PMError:
+            nat = ("err", None)
+        assert py == nat, (it, [x[1] for x in texts])
+        agree[py[0]] += 1
+    assert agree["ok"] > 30 and agree["err"] > 30

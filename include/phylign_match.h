@@ -298,6 +298,12 @@ int  pm_query_text(pm_index_t* idx, const char* fasta, size_t fasta_len,
 /* keep = -n of filter_queries.py (config nb_best_hits).  The queries handle must
  * outlive the merge. */
 int  pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out);
+/* the next PIECE of the same query file (a 01_queries_merged file that is parsed and searched piece by piece): its
+ * records continue the numbering.  The consumer's dict semantics hold through the whole file
+ * (scripts/filter_queries.py:107-120, :178-185): a read name is one query -- printed where it first occurs, with the
+ * sequence of its last occurrence and the matches of all its occurrences (the two mates of a read pair in
+ * concatenated files, Snakefile:336-352).  The piece must outlive the merge. */
+int  pm_merge_extend(pm_merge_t* m, const pm_queries_t* piece);
 /* adds the 03_match content of one batch: records of `slot` (count records are
  * skipped), post-filtered with nb_best_hits like pm_format_hits (>= 0) or taken
  * as they are (< 0); `batch` is the batch name of the file name
@@ -306,6 +312,11 @@ int  pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out);
  * from several threads (serialised inside). */
 int  pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* idx,
                   const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits);
+/* the same for records of a search with piece `piece` of the query file (0 = the set of pm_merge_create, 1 ... the
+ * pieces of pm_merge_extend in their order): their query numbers count inside that piece; piece = -1: they count
+ * through the whole file (pm_merge_export's records).  A batch added once per piece is one batch. */
+int  pm_merge_add_piece(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* idx,
+                        const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best_hits);
 /* adds the 03_match TEXT of one batch (the content of "<batch>____<qfile>.gz" after gunzip) -- the native
  * form of the reader of scripts/filter_queries.py:27-66 behind the drop-in scripts/filter_queries.py:
  * "*<qname>[ comment]\t<N>" starts a query, every other non-empty line is "<rnd>_<ref> <kmers>" (two fields,
@@ -313,13 +324,15 @@ int  pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* idx,
  * with PM_EINVAL like the reference raises (match lines ahead of the first header join the first query, as
  * they do there). */
 int  pm_merge_add_text(pm_merge_t* m, const char* batch, const char* text, size_t len);
-/* What the merge holds so far, as hit records {query, doc, score, slot = ordinal of the pm_merge_add
- * call that brought the batch} ordered by (slot, query, score desc, doc asc): one rank's share of the
+/* What the merge holds so far, as hit records {query (numbered through the whole file), doc, score, slot = number of
+ * the batch in this merge: pm_merge_batches} ordered by (slot, query, score desc, doc asc): one rank's share of the
  * 04_filter result.  The ranks of a multi-GPU stage gather these (the single RCCL gather at the end)
- * and rank 0 adds them again batch by batch with nb_best_hits < 0: the `keep` best (+ ties) of the
+ * and rank 0 adds them again batch by batch (pm_merge_add_piece, piece -1, nb_best_hits < 0): the `keep` best (+ ties) of the
  * union are among the `keep` best (+ ties) of every part, so the result equals the one-process merge
  * (scripts/filter_queries.py:123-156 prunes the same way file after file).  *hits malloc'd, pm_free(). */
 int  pm_merge_export(const pm_merge_t* m, pm_hit_t** hits, uint64_t* n);
+/* the batch names of the merge in the order of their numbers, '\n'-terminated each; *names malloc'd, pm_free() */
+int  pm_merge_batches(const pm_merge_t* m, char** names, size_t* len);
 /* ">qname ref1,ref2,...\nseq\n" per query in FASTA order; *text malloc'd, pm_free() */
 int  pm_merge_emit(const pm_merge_t* m, char** text, size_t* len);
 /* the same text written to `path` (via "<path>.tmp" + rename), built and written on several threads;

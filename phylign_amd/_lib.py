@@ -109,6 +109,9 @@ SYMBOLS = [
     ("pm_merge_add_text", C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("pm_merge_export", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_merge_emit", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pm_merge_extend", C.c_int, [_P, _P]),
+    ("pm_merge_add_piece", C.c_int, [_P, C.c_int64, C.c_char_p, _P, _P, C.c_uint64, C.c_uint32, C.c_int64]),
+    ("pm_merge_batches", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("pm_merge_emit_file", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
     ("pm_merge_emit_file_piece", C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]),
     ("pm_merge_free", None, [_P]),
@@ -486,18 +489,33 @@ class Merge:
     def __init__(self, queries: Queries, keep=100):
         h = _P()
         _chk(load().pm_merge_create(queries._h, keep, C.byref(h)))
-        self._h, self._q = h, queries
+        self._h, self._q = h, [queries]
 
-    def add(self, batch: str, index: Index, hits, slot=0, nb_best_hits=-1):
+    def extend(self, queries: Queries):
+        """the next piece of the same query file (its records continue the numbering; names are one namespace)"""
+        _chk(load().pm_merge_extend(self._h, queries._h))
+        self._q.append(queries)
+
+    def add(self, batch: str, index: Index, hits, slot=0, nb_best_hits=-1, piece=0):
+        """piece: the records' query numbers count inside that piece of the query file; -1: through the whole file"""
         hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
-        _chk(load().pm_merge_add(self._h, batch.encode(), index._h, hits.ctypes.data, hits.size, slot, nb_best_hits))
+        _chk(load().pm_merge_add_piece(self._h, piece, batch.encode(), index._h, hits.ctypes.data, hits.size, slot, nb_best_hits))
+
+    def batches(self):
+        """batch names in the order of their numbers (the `slot` of export()'s records)"""
+        t, n = _P(), C.c_size_t()
+        _chk(load().pm_merge_batches(self._h, C.byref(t), C.byref(n)))
+        out = C.string_at(t.value, n.value).decode()
+        load().pm_free(t)
+        return out.split("\n")[:-1] if out else []
 
     def add_text(self, batch: str, text: bytes):
         """the 03_match text of one batch (after gunzip), as scripts/filter_queries.py reads it"""
         _chk(load().pm_merge_add_text(self._h, batch.encode(), text, len(text)))
 
     def export(self):
-        """what is kept so far as a HIT_DTYPE array (slot = ordinal of the add() call that brought the batch)"""
+        """what is kept so far as a HIT_DTYPE array (query numbered through the whole file, slot = number of the batch:
+        batches())"""
         p, n = _P(), C.c_uint64()
         _chk(load().pm_merge_export(self._h, C.byref(p), C.byref(n)))
         buf = (C.c_char * (n.value * HIT_DTYPE.itemsize)).from_address(p.value) if n.value else b""

@@ -415,17 +415,29 @@ struct MergeBatch {
     std::vector<uint32_t> ref_rank;     // position of the document's reference name in the batch's sorted names
 };
 struct pm_merge {
-    const pm_queries* q = nullptr;
+    // the query file: one query set, or several PIECES of it in file order (pm_merge_extend: a file that is parsed and
+    // searched piece by piece); records are numbered through the pieces.  The sets outlive the merge: names and
+    // sequences are views into them.
+    std::vector<const pm_queries*> pieces;
+    std::vector<uint32_t> piece_base;                         // global number of a piece's first record (+ the total at the end)
     uint32_t keep = 0;
     std::vector<MergeBatch> batches;
-    // query name (readfq: the header up to its first space) -> record index.  A flat open-addressing table over views
-    // into the query set's header strings (the query set outlives the merge): a million std::string keys in an
-    // unordered_map cost 0.2-0.6 s to build, serially, before the first search of the stage could start.
+    std::unordered_map<std::string, uint32_t> batch_id;      // batch name -> its (first) entry in `batches`
+    // query name (readfq: the header up to its first space) -> record.  A flat open-addressing table over views
+    // into the query sets' header strings: a million std::string keys in an unordered_map cost 0.2-0.6 s to build,
+    // serially, before the first search of the stage could start.  The consumer's dict semantics
+    // (scripts/filter_queries.py:107-120, :178-185): a name is ONE query -- printed where it first occurs, with the
+    // sequence of its last occurrence, and with the matches of all its occurrences; so the table maps a name to its
+    // FIRST record (canon[] of every record with that name), and last_of[] of that record is the last one.
     std::vector<const char*> qname_p;
     std::vector<uint32_t> qname_n;
-    std::vector<uint32_t> table;                              // record index or kEmpty
+    std::vector<const char*> seq_p;
+    std::vector<uint32_t> seq_n;
+    std::vector<uint64_t> name_hash;                          // kept: the table is rebuilt when it grows
+    std::vector<uint32_t> table;                              // record number or kEmpty
     uint32_t mask = 0;
-    std::vector<uint32_t> canon;                              // canon[i]: the record a lookup of query i's name finds (dict: the last one wins)
+    std::vector<uint32_t> canon;                              // canon[i]: the first record with record i's name
+    std::vector<uint32_t> last_of;                            // for a first record: the last record with its name
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
     static uint64_t hash_name(const char* p, size_t n) {
         uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
@@ -435,7 +447,7 @@ struct pm_merge {
         return h * 0xC4CEB9FE1A85EC53ull;
     }
     // the table is 2^region_bits regions (top bits of the hash), probing wraps inside a region: regions are filled by
-    // different threads, each in record order (so "the last one wins" holds)
+    // different threads, each in record order (so "first" and "last" are what they are in the file)
     uint32_t region_bits = 0;
     bool dup_names = false, tab_names = false;                // a repeated query name / a TAB inside one: pm_merge_add stays on one thread
     uint32_t slot0(uint64_t h, uint32_t* base, uint32_t* rmask) const {
@@ -504,73 +516,119 @@ static int merge_settle(pm_merge* m, uint32_t target, size_t before, bool presor
     return PM_OK;
 }
 
-extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
-    if (!q || !out) return fail(PM_EINVAL, "bad argument");
-    pm_merge* m = new pm_merge();
-    m->q = q; m->keep = keep;
-    const size_t nq = q->headers.size();
-    if (nq >= 0x7FFFFFFFull) { delete m; return fail(PM_ERANGE, "too many queries for one merge"); }
-    m->items.resize(nq); m->floor_.assign(nq, 0);
-    m->qname_p.resize(nq); m->qname_n.resize(nq); m->canon.resize(nq);
-    size_t cap = 16;
-    while (cap < 2 * nq) cap <<= 1;
-    if (nq >= (1u << 16)) { cap <<= 1; m->region_bits = 4; }      // regions at a quarter load: none can fill up
-    m->table.assign(cap, pm_merge::kEmpty);
-    m->mask = (uint32_t)(cap - 1);
+// the records [first, end) are new: into the name table, region by region on several threads; a full region grows the table
+static void merge_index_names(pm_merge* m, size_t first) {
+    const size_t end = m->qname_p.size();
+    for (;;) {
+        const size_t regions = (size_t)1 << m->region_bits;
+        std::atomic<bool> full(false);
+        parallel_for(regions, [&](size_t r) {
+            const uint32_t rsize = (m->mask + 1u) >> m->region_bits;
+            size_t used = 0;
+            if (first)                                          // slots taken so far (a region's share is small: counted, not stored)
+                for (uint32_t k = 0; k < rsize; ++k) used += m->table[(uint32_t)r * rsize + k] != pm_merge::kEmpty;
+            for (size_t i = first; i < end; ++i) {
+                if ((m->name_hash[i] >> (64 - m->region_bits)) != r) continue;
+                uint32_t base, rmask;
+                const char* p = m->qname_p[i]; const size_t n = m->qname_n[i];
+                for (uint32_t s2 = m->slot0(m->name_hash[i], &base, &rmask);; s2 = (s2 + 1) & rmask) {
+                    const uint32_t o = m->table[base + s2];
+                    if (o == pm_merge::kEmpty) {
+                        if (++used > rmask) { full.store(true); return; }       // would leave no empty slot: probing needs one
+                        m->table[base + s2] = (uint32_t)i;
+                        m->canon[i] = (uint32_t)i; m->last_of[i] = (uint32_t)i;
+                        break;
+                    }
+                    if (m->qname_n[o] == n && memcmp(m->qname_p[o], p, n) == 0) {       // the name of an earlier record
+                        m->canon[i] = o; m->last_of[o] = (uint32_t)i;
+                        break;
+                    }
+                }
+            }
+        });
+        if (!full.load()) return;
+        // a region ran full (names whose hashes crowd it, or the table is simply too small by now): twice the slots, all
+        // records again
+        m->table.assign(m->table.size() * 2, pm_merge::kEmpty);
+        m->mask = (uint32_t)(m->table.size() - 1);
+        first = 0;
+    }
+}
+
+extern "C" int pm_merge_extend(pm_merge_t* m, const pm_queries_t* q) {
+    if (!m || !q) return fail(PM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t old = m->qname_p.size(), nq = q->headers.size(), total = old + nq;
+    if (total >= 0x7FFFFFFFull) return fail(PM_ERANGE, "too many queries for one merge");
+    m->pieces.push_back(q);
+    m->piece_base.back() = (uint32_t)old;
+    m->piece_base.push_back((uint32_t)total);
+    m->items.resize(total); m->floor_.resize(total, 0);
+    m->qname_p.resize(total); m->qname_n.resize(total); m->seq_p.resize(total); m->seq_n.resize(total);
+    m->name_hash.resize(total); m->canon.resize(total); m->last_of.resize(total);
     const size_t nt = std::max<size_t>(1, std::min<size_t>(parallel_width(), nq / 65536));
-    std::vector<uint64_t> hashes(nq);
+    std::atomic<bool> tabs(false);
     parallel_for(nt, [&](size_t t) {
         for (size_t i = nq * t / nt; i < nq * (t + 1) / nt; ++i) {
             // readfq name: the header up to its first space (scripts/filter_queries.py:80)
             const std::string& h = q->headers[i];
             const void* sp = memchr(h.data(), ' ', h.size());
-            m->qname_p[i] = h.data();
-            m->qname_n[i] = (uint32_t)(sp ? (size_t)((const char*)sp - h.data()) : h.size());
-            hashes[i] = pm_merge::hash_name(m->qname_p[i], m->qname_n[i]);
+            const size_t g = old + i;
+            m->qname_p[g] = h.data();
+            m->qname_n[g] = (uint32_t)(sp ? (size_t)((const char*)sp - h.data()) : h.size());
+            m->seq_p[g] = q->seqs.data() + q->seq_off[i];
+            m->seq_n[g] = (uint32_t)(q->seq_off[i + 1] - q->seq_off[i]);
+            m->name_hash[g] = pm_merge::hash_name(m->qname_p[g], m->qname_n[g]);
+            if (memchr(m->qname_p[g], '\t', m->qname_n[g])) tabs.store(true, std::memory_order_relaxed);
         }
     });
-    for (;;) {
-        const size_t regions = (size_t)1 << m->region_bits;
-        std::atomic<bool> full(false);
-        parallel_for(regions, [&](size_t r) {                   // duplicates: the last record wins, as in a dict
-            size_t used = 0;
-            for (size_t i = 0; i < nq; ++i) {
-                if (m->region_bits && (hashes[i] >> (64 - m->region_bits)) != r) continue;
-                uint32_t base, rmask;
-                const char* p = m->qname_p[i]; const size_t n = m->qname_n[i];
-                for (uint32_t s2 = m->slot0(hashes[i], &base, &rmask);; s2 = (s2 + 1) & rmask) {
-                    const uint32_t o = m->table[base + s2];
-                    if (o == pm_merge::kEmpty) {
-                        if (++used > rmask) { full.store(true); return; }       // would leave no empty slot: probing needs one
-                        m->table[base + s2] = (uint32_t)i;
-                        break;
-                    }
-                    if (m->qname_n[o] == n && memcmp(m->qname_p[o], p, n) == 0) { m->table[base + s2] = (uint32_t)i; break; }
-                }
-            }
-        });
-        if (!full.load()) break;
-        // names whose hashes crowd one region (never seen with real read names): one region, at most half full
-        m->region_bits = 0;
-        std::fill(m->table.begin(), m->table.end(), pm_merge::kEmpty);
+    // the table holds at most a quarter of its slots (a region: at most all but one)
+    size_t cap = std::max<size_t>(m->table.size(), 256);
+    while (cap < 4 * total) cap <<= 1;
+    size_t first = old;
+    if (cap != m->table.size()) {
+        m->table.assign(cap, pm_merge::kEmpty);
+        m->mask = (uint32_t)(cap - 1);
+        first = 0;
     }
-    std::atomic<bool> dups(false), tabs(false);
-    parallel_for(nt, [&](size_t t) {
-        for (size_t i = nq * t / nt; i < nq * (t + 1) / nt; ++i) {
-            m->canon[i] = m->lookup(m->qname_p[i], m->qname_n[i]);
-            if (m->canon[i] != i) dups.store(true, std::memory_order_relaxed);
-            if (memchr(m->qname_p[i], '\t', m->qname_n[i])) tabs.store(true, std::memory_order_relaxed);
-        }
-    });
-    m->dup_names = dups.load(); m->tab_names = tabs.load();
+    merge_index_names(m, first);
+    if (!m->dup_names)
+        for (size_t g = old; g < total; ++g) if (m->canon[g] != g) { m->dup_names = true; break; }
+    m->tab_names = m->tab_names || tabs.load();
+    return PM_OK;
+}
+
+extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
+    if (!q || !out) return fail(PM_EINVAL, "bad argument");
+    pm_merge* m = new pm_merge();
+    m->keep = keep;
+    m->region_bits = 4;
+    m->piece_base.push_back(0);
+    const int rc = pm_merge_extend(m, q);
+    if (rc) { delete m; return rc; }
     *out = m;
     return PM_OK;
 }
 
+static int merge_add_impl(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* ix,
+                          const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best);
 extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* ix,
                             const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
+    return merge_add_impl(m, 0, batch, ix, hits, n_hits, slot, nb_best);
+}
+// the records' query numbers count inside piece `piece` of the query file (pm_merge_extend), or -- piece = -1 -- through
+// the whole file (what pm_merge_export writes: another rank's kept matches)
+extern "C" int pm_merge_add_piece(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* ix,
+                                  const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
+    return merge_add_impl(m, piece, batch, ix, hits, n_hits, slot, nb_best);
+}
+static int merge_add_impl(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* ix,
+                          const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
     if (!m || !batch || !ix || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
-    const size_t nq = m->q->headers.size();
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (piece < -1 || piece >= (int64_t)m->pieces.size()) return fail(PM_EINVAL, "piece %lld of a merge over %zu pieces", (long long)piece, m->pieces.size());
+    const size_t qbase = piece < 0 ? 0 : m->piece_base[(size_t)piece];
+    const size_t nq = piece < 0 ? m->qname_p.size() : (size_t)(m->piece_base[(size_t)piece + 1] - m->piece_base[(size_t)piece]);
     // the slot's records: a contiguous slice when the input is ordered (what pm_result_hits_* deliver),
     // else copied out and ordered
     std::vector<pm_hit_t> copy;
@@ -587,12 +645,9 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
     for (size_t i = 0; i < n_mine; ++i)
         if (mine[i].query >= nq || (mine[i].doc != PM_DOC_COUNT && mine[i].doc >= ix->info.n_docs))
             return fail(PM_EINVAL, "hit record out of range for batch %s", batch);
-    std::lock_guard<std::mutex> lk(m->mu);
     // reference names of this batch ("<rnd>_<ref>" -> "<ref>", exactly one '_': scripts/filter_queries.py:64);
     // a malformed name is an error only if a kept record uses it, like the consumer's tuple unpacking
-    const uint32_t bid = (uint32_t)m->batches.size();
-    m->batches.emplace_back();
-    MergeBatch& mb = m->batches.back();
+    MergeBatch mb;
     mb.name = batch;
     mb.ref_off.resize((size_t)ix->info.n_docs + 1);
     std::vector<uint8_t> bad_name((size_t)ix->info.n_docs, 0);
@@ -606,7 +661,13 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
         mb.refs.push_back('\0');
     }
     mb.ref_off[ix->info.n_docs] = (uint32_t)mb.refs.size();
-    {   // rank of every reference name inside the batch: ordering the items of one batch needs no string compare
+    // a batch is added once per piece of the query file: its name table is kept once
+    uint32_t bid = (uint32_t)m->batches.size();
+    {
+        auto it = m->batch_id.find(mb.name);
+        if (it != m->batch_id.end() && m->batches[it->second].refs == mb.refs && m->batches[it->second].ref_off == mb.ref_off) bid = it->second;
+    }
+    if (bid == m->batches.size()) {   // rank of every reference name inside the batch: ordering the items of one batch needs no string compare
         std::vector<uint32_t> order((size_t)ix->info.n_docs);
         for (uint32_t d = 0; d < ix->info.n_docs; ++d) order[d] = d;
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
@@ -619,6 +680,8 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
             if (i && strcmp(mb.refs.data() + mb.ref_off[order[i]], mb.refs.data() + mb.ref_off[order[i - 1]]) != 0) r = (uint32_t)i;
             mb.ref_rank[order[i]] = r;
         }
+        m->batch_id.emplace(mb.name, bid);                  // (a second table under the same name keeps its own number)
+        m->batches.push_back(std::move(mb));
     }
     // records [pa, pb) (whole queries): distinct queries have distinct targets unless the query file repeats a name, so
     // ranges of queries can be merged on several threads; the first error in record order is the one reported
@@ -634,12 +697,13 @@ extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* 
             // the 03_match header is "*<header>\tN": the consumer looks the query up by the text
             // before the first TAB, cut at the first space (scripts/filter_queries.py:58-59)
             // (a name holds no TAB in practice: then that text is the query's own name and the lookup is canon[])
-            uint32_t target = m->canon[qi];
-            if (const void* tab = memchr(m->qname_p[qi], '\t', m->qname_n[qi])) {
-                const size_t kn = (size_t)((const char*)tab - m->qname_p[qi]);
-                target = m->lookup(m->qname_p[qi], kn);
+            const size_t gq = qbase + qi;
+            uint32_t target = m->canon[gq];
+            if (const void* tab = memchr(m->qname_p[gq], '\t', m->qname_n[gq])) {
+                const size_t kn = (size_t)((const char*)tab - m->qname_p[gq]);
+                target = m->lookup(m->qname_p[gq], kn);
                 if (target == pm_merge::kEmpty) {
-                    snprintf(msg, sizeof msg, "query '%.*s' of batch %s is not in the query file", (int)kn, m->qname_p[qi], batch);
+                    snprintf(msg, sizeof msg, "query '%.*s' of batch %s is not in the query file", (int)kn, m->qname_p[gq], batch);
                     err = msg;
                     return PM_EINVAL;
                 }
@@ -794,8 +858,8 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
     return PM_OK;
 }
 
-// What is kept so far as hit records {query, doc, score, slot = number of the pm_merge_add call that
-// brought the batch}, ordered by (slot, query, score desc, doc asc): a rank's share of the 04_filter
+// What is kept so far as hit records {query (numbered through the whole file), doc, score, slot = number of the batch
+// in this merge: pm_merge_batches}, ordered by (slot, query, score desc, doc asc): a rank's share of the 04_filter
 // merge, ready to be gathered (RCCL) and added again on rank 0 -- the best `keep` (+ ties) of the
 // union are among the best `keep` (+ ties) of every part.
 extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n) {
@@ -814,6 +878,21 @@ extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n
     return PM_OK;
 }
 
+// the batches of the merge in the order of their numbers (the `slot` of pm_merge_export's records), '\n'-separated
+extern "C" int pm_merge_batches(const pm_merge_t* m_, char** names, size_t* len) {
+    pm_merge* m = const_cast<pm_merge*>(m_);
+    if (!m || !names || !len) return fail(PM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    std::string out;
+    for (const MergeBatch& b : m->batches) { out += b.name; out.push_back('\n'); }
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) return fail(PM_ENOMEM, "out of host memory");
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *names = buf; *len = out.size();
+    return PM_OK;
+}
+
 // The 04_filter FASTA in blocks of records: exact sizes first (the text is a concatenation of known strings), then every
 // block is formatted straight to its place -- into the caller's buffer, or through a pooled scratch buffer and
 // pwrite() into the file -- on several threads.  Nothing the size of the output is allocated, touched twice or copied.
@@ -823,20 +902,11 @@ struct EmitPlan {
     std::vector<uint64_t> off;            // byte offset of block b; off.back() = total
 };
 static void merge_emit_plan(const pm_merge* m, EmitPlan& pl) {
-    const pm_queries* q = m->q;
-    const size_t nq = q->headers.size();
+    const size_t nq = m->qname_p.size();
     // dict semantics of the consumer: one record per distinct name, at the position of its
     // first occurrence, with the sequence of its last occurrence
     pl.recs.reserve(nq);
-    {
-        std::vector<char> seen(nq, 0);
-        for (size_t i = 0; i < nq; ++i) {
-            const uint32_t rec = m->canon[i];
-            if (seen[rec]) continue;
-            seen[rec] = 1;
-            pl.recs.push_back(rec);
-        }
-    }
+    for (size_t i = 0; i < nq; ++i) if (m->canon[i] == i) pl.recs.push_back((uint32_t)i);
     constexpr size_t kBlock = 4096;
     const size_t nb = (pl.recs.size() + kBlock - 1) / kBlock;
     pl.first.resize(nb + 1);
@@ -849,7 +919,7 @@ static void merge_emit_plan(const pm_merge* m, EmitPlan& pl) {
             for (size_t k = pl.first[b]; k < pl.first[b + 1]; ++k) {
                 const uint32_t rec = pl.recs[k];
                 const std::vector<MergeItem>& v = m->items[rec];
-                bytes += 1 + m->qname_n[rec] + 1 + (v.empty() ? 0 : v.size() - 1) + 1 + (uint64_t)(q->seq_off[rec + 1] - q->seq_off[rec]) + 1;
+                bytes += 1 + m->qname_n[rec] + 1 + (v.empty() ? 0 : v.size() - 1) + 1 + (uint64_t)m->seq_n[m->last_of[rec]] + 1;
                 for (const MergeItem& it : v) { size_t rl; (void)m->ref(it, &rl); bytes += rl; }
             }
             pl.off[b + 1] = bytes;
@@ -858,7 +928,6 @@ static void merge_emit_plan(const pm_merge* m, EmitPlan& pl) {
     for (size_t b = 0; b < nb; ++b) pl.off[b + 1] += pl.off[b];
 }
 static char* merge_emit_block(const pm_merge* m, const EmitPlan& pl, size_t b, char* w) {
-    const pm_queries* q = m->q;
     for (size_t k = pl.first[b]; k < pl.first[b + 1]; ++k) {
         const uint32_t rec = pl.recs[k];
         *w++ = '>'; memcpy(w, m->qname_p[rec], m->qname_n[rec]); w += m->qname_n[rec]; *w++ = ' ';
@@ -869,8 +938,8 @@ static char* merge_emit_block(const pm_merge* m, const EmitPlan& pl, size_t b, c
             memcpy(w, r, rl); w += rl;
         }
         *w++ = '\n';
-        const size_t sl = (size_t)(q->seq_off[rec + 1] - q->seq_off[rec]);
-        memcpy(w, q->seqs.data() + q->seq_off[rec], sl); w += sl;
+        const uint32_t sr = m->last_of[rec];
+        memcpy(w, m->seq_p[sr], m->seq_n[sr]); w += m->seq_n[sr];
         *w++ = '\n';
     }
     return w;

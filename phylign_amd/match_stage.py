@@ -191,8 +191,8 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     `batches`).  `queries` is one pm.Queries or a LIST of them (or of Futures of them: a file that is still being parsed):
     the chunks, in file order, of a query file with more reads than fit HBM at once, or of one cut up so that parsing and
     searching overlap -- every group of resident batches is then searched chunk after chunk (the pipeline's units are
-    (group, chunk) pairs), a batch's file grows by one piece per chunk, and there is one merge per chunk.  Returns
-    (report dict, pm.Merge / list of pm.Merge / None).  keep_texts: optional dict that receives {batch: post-filtered text}
+    (group, chunk) pairs), a batch's file grows by one piece per chunk, and the ONE 04_filter merge is extended chunk by
+    chunk (read names are one namespace through the whole file).  Returns (report dict, pm.Merge or None).  keep_texts: optional dict that receives {batch: post-filtered text}
     (tests)."""
     from . import pgzip
     t_start = time.perf_counter()
@@ -202,7 +202,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     nb = nb_best_hits
     budget = budget_bytes if budget_bytes else 0.6 * pm.device_info()["hbm_free"]
     admit = Admission(budget)
-    merges = [None] * nc if want_merge else None
+    merge = [None]                                   # the ONE 04_filter merge of the query file, extended piece by piece
     # a chunk may arrive as a Future of its pm.Queries (the file is still being parsed): chunks are made ready in order --
     # parsed, and their merge state created -- by one thread that runs ahead of the searches
     prepared, prep_err = [threading.Event() for _ in range(nc)], []
@@ -213,7 +213,10 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
                 if hasattr(chunks[ci], "result"):
                     chunks[ci] = chunks[ci].result()
                 if want_merge:
-                    merges[ci] = pm.Merge(chunks[ci], keep=nb)
+                    if ci == 0:
+                        merge[0] = pm.Merge(chunks[0], keep=nb)
+                    else:
+                        merge[0].extend(chunks[ci])    # read names are one namespace through the whole file
             except BaseException as e:                   # noqa: BLE001 -- handed to the thread that asks for the chunk
                 prep_err.append(e)
             prepared[ci].set()
@@ -231,7 +234,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     ready, ready_cv, failed = [], threading.Condition(), []
     acc = {"load_s": 0.0, "format_s": 0.0, "gzip_s": 0.0, "merge_s": 0.0, "match_only_s": 0.0, "gpu_wait_s": 0.0,
            "d2h_s": 0.0}
-    acc_mu, merge_mu, merge_orders = threading.Lock(), threading.Lock(), [[] for _ in chunks]
+    acc_mu = threading.Lock()
 
     def add_time(key, dt):
         with acc_mu:
@@ -314,13 +317,11 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
                     pgzip.write(path, keep_texts[b], level=1, pool=deflaters)
                 tc = tc0 = time.perf_counter()
             td = tc
-            if merges is not None:
-                with merge_mu:                           # the library serialises adds anyway; the ordinal of the add is the export's slot
-                    tc = time.perf_counter()             # (time spent waiting for the lock is not merge work)
-                    merges[ci].add(b, ix, part, slot=i, nb_best_hits=nb)
-                    merge_orders[ci].append(b)
-                    td = time.perf_counter()
-            add_time("format_s", tb - ta); add_time("gzip_s", (tc if merges is None else tc0) - tb); add_time("merge_s", td - tc)
+            if want_merge:
+                tc = time.perf_counter()                 # (the library serialises adds: waiting for another batch's add counts here)
+                merge[0].add(b, ix, part, slot=i, nb_best_hits=nb, piece=ci)
+                td = time.perf_counter()
+            add_time("format_s", tb - ta); add_time("gzip_s", tc0 - tb); add_time("merge_s", td - tc)
             return len(part)
         n_rec = list(workers.map(one, range(len(group))))
         res.free()
@@ -382,10 +383,8 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
               "format_s_thread_sum": round(acc["format_s"], 3), "gzip_s_thread_sum": round(acc["gzip_s"], 3),
               "format_and_gzip_in_library": keep_texts is None,
               "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
-              "per_group": group_rows, "merge_order": merge_orders[0] if nc == 1 else merge_orders}
-    if merges is None:
-        return report, None
-    return report, (merges if isinstance(queries, (list, tuple)) else merges[0])
+              "per_group": group_rows, "merge_order": merge[0].batches() if want_merge else []}
+    return report, merge[0]
 
 
 def bind_rank_to_gpu(local_rank, n_visible):
@@ -492,42 +491,41 @@ def main(argv=None):
     if args.loaders <= 0:
         from .sysinfo import effective_cpus
         args.loaders = max(4, min(16, effective_cpus() - 4))
-    report, merges = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
-                               want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
-                               max_group=args.max_group, kmer_size=args.kmer_size)
+    report, merge = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
+                              want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
+                              max_group=args.max_group, kmer_size=args.kmer_size)
     parser.shutdown()
     del fasta
-    orders = report["merge_order"] if len(chunk_list) > 1 else [report["merge_order"]]
 
-    # ---- 04_filter: per chunk one gather of what every rank's merge kept, rank 0 adds the parts and emits
+    # ---- 04_filter: ONE gather of what every rank's merge kept (queries numbered through the whole file, slot = the
+    # batch's number in that rank's merge), rank 0 adds the parts and emits
     t_f = time.perf_counter()
     if args.filter_out:
         if world > 1:
-            for ci, merge in enumerate(merges):
-                ex = merge.export()                                  # slot = ordinal of the add = position in the chunk's merge order
-                t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
-                if backend == "nccl":
-                    t = t.cuda()
-                g = gather_hits(t, dst=0)
-                meta = [None] * world if rank == 0 else None
-                dist.gather_object((len(ex), orders[ci]), meta, dst=0)
-                if rank == 0:
-                    allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
-                    off = 0
-                    for r, (n, r_order) in enumerate(meta):
-                        part = allrec[off:off + n]
-                        off += n
-                        if r == 0:
-                            continue                                  # rank 0's own matches are in `merge` already
-                        cut = np.searchsorted(part["slot"], np.arange(len(r_order) + 1, dtype=np.uint32))
-                        for k, b in enumerate(r_order):
-                            if cut[k + 1] > cut[k]:
-                                nix = names_index(pm, source, b)
-                                merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1)
-                                nix.free()
+            ex = merge.export()
+            t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
+            if backend == "nccl":
+                t = t.cuda()
+            g = gather_hits(t, dst=0)
+            meta = [None] * world if rank == 0 else None
+            dist.gather_object((len(ex), report["merge_order"]), meta, dst=0)
+            if rank == 0:
+                allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+                off = 0
+                for r, (n, r_order) in enumerate(meta):
+                    part = allrec[off:off + n]
+                    off += n
+                    if r == 0:
+                        continue                                  # rank 0's own matches are in `merge` already
+                    cut = np.searchsorted(part["slot"], np.arange(len(r_order) + 1, dtype=np.uint32))
+                    for k, b in enumerate(r_order):
+                        if cut[k + 1] > cut[k]:
+                            nix = names_index(pm, source, b)
+                            merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1, piece=-1)
+                            nix.free()
         if rank == 0:
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
-            report["filter_fasta_bytes"] = pm.emit_merges_to(merges, args.filter_out)   # chunks are in file order: so are the records
+            report["filter_fasta_bytes"] = merge.emit_to(args.filter_out)
     report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
     if world > 1:
         dist.barrier()

@@ -1173,3 +1173,75 @@ def test_native_match_text_reader_against_the_mirror_on_random_odd_input(tmp_pat
         assert py == nat, (it, [x[1] for x in texts])
         agree[py[0]] += 1
     assert agree["ok"] > 30 and agree["err"] > 30
+
+
+@pytest.mark.parametrize("keep", [1, 3])
+def test_merge_over_pieces_of_a_query_file_keeps_the_whole_files_dict_semantics(tmp_path, keep):
+    """a query file in pieces (pm_merge_extend) whose read names repeat ACROSS pieces -- the two mates of a read pair in
+    concatenated files: the merge over the pieces emits exactly what one merge over the whole file emits, which is what
+    the mirror of scripts/filter_queries.py (a dict keyed by name) writes: one record per name where it first occurs,
+    the last occurrence's sequence, the best matches of all occurrences together"""
+    import gzip
+    import io
+    from phylign_amd import _lib as pm
+    from phylign_amd import filter_queries as F
+    from phylign_amd.match_stage import split_prepared_fasta
+    rng = np.random.default_rng(81 + keep)
+    n = 3000
+    names = [f"read{i}" for i in range(n)]
+    mates = [f"read{i}" for i in rng.permutation(n)[: n // 2]]                  # second file: mates of half of the reads
+    extra = [f"solo{i}" for i in range(200)]
+    allq = names + mates + extra + [names[5], names[5]]
+    fasta = "".join(f">{nm} c{i}\n{'ACGT' * 8}{'ACGTACGTT'[: 1 + i % 9]}\n" for i, nm in enumerate(allq)).encode()
+    nq = len(allq)
+    ixs = [pm.Index.from_names([f"{d:03x}_R{b}x{d}" for d in range(40)]) for b in range(3)]
+    whole_q = pm.Queries(fasta)
+    recs = []
+    for b in range(3):
+        hq = np.sort(rng.choice(nq, size=nq // 2, replace=False)).astype(np.uint32)
+        r = np.zeros(len(hq) * 2, dtype=pm.HIT_DTYPE)
+        r["query"] = np.repeat(hq, 2)
+        r["doc"] = rng.integers(0, 40, len(r))
+        r["score"] = rng.integers(1, 6, len(r))
+        recs.append(pm.sort_hits(r))
+    whole = pm.Merge(whole_q, keep)
+    for b in range(3):
+        whole.add(f"b{b}", ixs[b], recs[b], slot=0, nb_best_hits=keep)
+    want = whole.emit()
+    # the mirror on the files the stage would write
+    (tmp_path / "q.fa").write_bytes(fasta)
+    files = []
+    for b in range(3):
+        fn = tmp_path / f"b{b}____q.gz"
+        with gzip.open(fn, "wb") as g:
+            g.write(pm.format_hits(ixs[b], whole_q, recs[b], slot=0, nb_best_hits=keep))
+        files.append(str(fn))
+    out = io.StringIO()
+    F.filter_files(str(tmp_path / "q.fa"), files, keep, out)
+    assert want.decode() == out.getvalue()
+    for size in (1000, 1777, nq - 1):
+        pieces = [pm.Queries(p) for p in split_prepared_fasta(fasta, size)]
+        m = pm.Merge(pieces[0], keep)
+        base = [0]
+        for p_ in pieces[1:]:
+            m.extend(p_)
+        for p_ in pieces:
+            base.append(base[-1] + p_.count()[0])
+        order = [(b, ci) for b in range(3) for ci in range(len(pieces))]
+        rng.shuffle(order)                                         # (batch, piece) units arrive in any order
+        for b, ci in order:
+            part = recs[b][(recs[b]["query"] >= base[ci]) & (recs[b]["query"] < base[ci + 1])].copy()
+            part["query"] -= base[ci]
+            m.add(f"b{b}", ixs[b], part, slot=0, nb_best_hits=keep, piece=ci)
+        assert m.emit() == want, size
+        assert sorted(m.batches()) == ["b0", "b1", "b2"]
+        # a rank's share exported and added again (numbers through the whole file, piece -1)
+        ex = m.export()
+        again = pm.Merge(pieces[0], keep)
+        for p_ in pieces[1:]:
+            again.extend(p_)
+        for k, bn in enumerate(m.batches()):
+            again.add(bn, ixs[int(bn[1:])], ex[ex["slot"] == k], slot=k, nb_best_hits=-1, piece=-1)
+        assert again.emit() == want
+    with pytest.raises(pm.PMError):
+        m.add("b0", ixs[0], recs[0][:0], piece=99)

@@ -132,7 +132,7 @@ def test_random_multi_index_search_text_identical(pm, oracle, seed):
 @pytest.mark.parametrize("seed", _seeds(12))
 def test_random_stage_run_files_and_fasta_identical(pm, oracle, tmp_path, seed):
     """match_stage.run_stage on random resident batches: random grouping (--max-group), the query file whole, in record
-    chunks or in byte pieces that arrive as Futures, repeated read names now and then -- every 03_match file equals the
+    chunks or in byte pieces that arrive as Futures, repeated read names now and then (also across pieces) -- every 03_match file equals the
     oracle's text after the post-filter, the 04_filter FASTA equals the (fixture-pinned) mirror of filter_queries.py"""
     import gzip
     import io
@@ -172,11 +172,10 @@ def test_random_stage_run_files_and_fasta_identical(pm, oracle, tmp_path, seed):
     else:
         qarg = [parser.submit(pm.Queries, p) for p in MS.split_prepared_fasta(fasta, 0, int(rng.integers(64, 4000)))]
     out_dir = tmp_path / "03_match"
-    report, merges = MS.run_stage(pm, batches, list(range(n_b)), src, qarg, "Q", str(out_dir), thr, n, want_merge=True,
-                                  max_group=int(rng.choice([0, 0, 1, 2, 3])))
+    report, merge = MS.run_stage(pm, batches, list(range(n_b)), src, qarg, "Q", str(out_dir), thr, n, want_merge=True,
+                                 max_group=int(rng.choice([0, 0, 1, 2, 3])))
     parser.shutdown()
-    merges = merges if isinstance(merges, list) else [merges]
-    assert report["queries"] == nq
+    assert report["queries"] == nq and sorted(report["merge_order"]) == sorted(batches)
     files = []
     for b in batches:
         exp = P.filter_text(oracle.query_file(indexes[b], fasta, thr).decode(), n)
@@ -186,12 +185,8 @@ def test_random_stage_run_files_and_fasta_identical(pm, oracle, tmp_path, seed):
     (tmp_path / "Q.fa").write_bytes(fasta)
     want = io.StringIO()
     F.filter_files(str(tmp_path / "Q.fa"), files, n, want)
-    got = pm.emit_merges_to(merges, str(tmp_path / "F.fa"))
-    if len(merges) == 1:
-        assert (tmp_path / "F.fa").read_text() == want.getvalue() and got == len(want.getvalue())
-    else:
-        # one merge per chunk: a name that repeats ACROSS chunks is one record per chunk here (DESIGN.md section 5,
-        # known deviations), so the whole-file mirror applies only when the names are unique
-        if len(set(names_q)) == nq:
-            assert (tmp_path / "F.fa").read_text() == want.getvalue()
+    # one merge over all pieces: a read name that repeats -- inside a piece or across pieces -- is one query, as in the
+    # consumer's dict
+    got = merge.emit_to(str(tmp_path / "F.fa"))
+    assert (tmp_path / "F.fa").read_text() == want.getvalue() and got == len(want.getvalue())
     assert not list(out_dir.glob("*.tmp"))

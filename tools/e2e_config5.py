@@ -96,16 +96,15 @@ def main():
                     return x
                 parser = ThreadPoolExecutor(max_workers=1)
                 stage_q = [parser.submit(parse_piece, p_) for p_ in MS.split_prepared_fasta(fasta, args.query_chunk, args.piece_mb << 20)]
-            report, merges = MS.run_stage(pm, names, list(range(len(names))), src, stage_q, "Q", out_dir, args.threshold,
+            report, merge = MS.run_stage(pm, names, list(range(len(names))), src, stage_q, "Q", out_dir, args.threshold,
                                           args.nb_best_hits, want_merge=True, max_group=mg)
             if args.piece_mb > 0:
                 parser.shutdown()
             t1 = time.perf_counter()
             os.makedirs(os.path.join(args.out, "04_filter"), exist_ok=True)
-            fasta_bytes = pm.emit_merges_to(merges, os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
+            fasta_bytes = merge.emit_to(os.path.join(args.out, "04_filter", f"Q_g{mg}.fa"))
             t2 = time.perf_counter()
-            for m_ in merges:
-                m_.free()
+            merge.free()
             if args.piece_mb > 0:                    # (a merge reads its query set's names: the sets go after the merges)
                 for f_ in stage_q:
                     f_.result().free()

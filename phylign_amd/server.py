@@ -226,13 +226,17 @@ class Dispatcher(threading.Thread):
                             slot_of[h] = len(uniq)
                             uniq.append(j["ix"])
                     res = self.pm.search(uniq, q, thr, nb_best_hits=0 if nb is None else max(int(nb), 0))
-                    hits = res.hits()                      # ordered by (slot, query, ...): handlers take their slot's slice
+                    per_slot = []
+                    for k in range(len(uniq)):             # every batch's records on their own: a handler formats only its own
+                        with res.slot_hits(k) as sl:
+                            per_slot.append(sl.hits.copy())
                     res.free()
                     self.searches += 1
                     self.fused_jobs += len(jobs)
                     self.max_fused = max(self.max_fused, len(uniq))
                     for j in jobs:
-                        j["queries"], j["hits"], j["slot"] = q, hits, slot_of[id(j["ix"])]
+                        k = slot_of[id(j["ix"])]
+                        j["queries"], j["hits"], j["slot"] = q, per_slot[k], k
                 except Exception as e:
                     for j in jobs:
                         j["error"] = e

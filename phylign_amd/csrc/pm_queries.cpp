@@ -206,9 +206,11 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
 
 // Rules `fix_query` + `concatenate_queries` (Snakefile:314-352) fused into the parser: what
 //   seqtk seq -A -U -C in | awk '{if(NR%2==1){print $0;}else{gsub(/[^ACGT]/, "A"); print;}}'
-// writes, read with kseq's record rules (seqtk's reader):
-//   * bytes before the first line that starts with '>' or '@' are skipped;
-//   * name = the header up to its first blank (space, TAB) -- the comment is dropped (-C);
+// writes, read with the record rules of kseq.h's kseq_read() (seqtk's reader; klib, restated here step by step):
+//   * at the start of the input and after every FASTQ record the reader jumps to the next '>' or '@' -- wherever in a
+//     line it stands; after a FASTA record the header is the line whose first byte ended the sequence;
+//   * name = the header up to its first white-space byte (isspace: blank, TAB, CR, VT, FF, newline) -- the rest of the
+//     line, the comment, is dropped (-C);
 //   * sequence = the following lines concatenated, up to a line that starts with '>', '@' or '+';
 //     empty lines are skipped, a trailing '\r' is dropped;
 //   * '+' starts a FASTQ quality block: the rest of that line is skipped, then quality lines are
@@ -218,54 +220,73 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
 //   * -U upper-cases, awk maps every byte that is not A, C, G or T to 'A';
 //   * a record without sequence is printed by seqtk as an empty line and ignored by cobs: dropped.
 // A sequence shorter than term_size stays an error (PM_EQUERY), exactly as for a prepared file.
+// The Python mirror (phylign_amd/fix_query.py) restates the same steps; the two are compared on random well- and
+// ill-formed input (tests/test_golden_cpu.py).
 static int parse_raw_normalised(pm_queries* q, const char* buf, size_t len) {
+    auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
     size_t p = 0;
-    auto next_line = [&](const char** line, size_t* ll) -> bool {        // false at end of input
-        if (p >= len) return false;
-        const char* nl = (const char*)memchr(buf + p, '\n', len - p);
-        size_t l = nl ? (size_t)(nl - (buf + p)) : len - p;
-        *line = buf + p;
-        p += l + (nl ? 1 : 0);
-        if (l && (*line)[l - 1] == '\r') --l;
-        *ll = l;
-        return true;
-    };
-    const char* line = nullptr; size_t ll = 0;
-    bool have = next_line(&line, &ll);
-    while (have && !(ll && (line[0] == '>' || line[0] == '@'))) have = next_line(&line, &ll);
+    int last = 0;                                             // kseq's last_char: a header byte that was read already
     std::string name, seq;
-    while (have) {
-        // `line` is a header line
-        size_t e = 1;
-        while (e < ll && line[e] != ' ' && line[e] != '\t') ++e;
-        name.assign(line + 1, e - 1);
+    for (;;) {
+        if (last == 0) {                                      // jump to the next header byte, anywhere
+            while (p < len && buf[p] != '>' && buf[p] != '@') ++p;
+            if (p >= len) break;
+            ++p;
+        }
+        if (p >= len) break;                                  // a header byte at the very end: no name to read
+        size_t e = p;
+        while (e < len && !is_space(buf[e])) ++e;
+        name.assign(buf + p, e - p);
         seq.clear();
-        have = next_line(&line, &ll);
-        while (have && !(ll && (line[0] == '>' || line[0] == '@' || line[0] == '+'))) {
-            seq.append(line, ll);
-            have = next_line(&line, &ll);
+        int c = -1;
+        if (e < len) {
+            p = e + 1;
+            if (buf[e] != '\n') {                             // the comment: to the end of the line
+                const char* nl = (const char*)memchr(buf + p, '\n', len - p);
+                p = nl ? (size_t)(nl - buf) + 1 : len;
+            }
+            // sequence lines
+            while (p < len) {
+                c = (unsigned char)buf[p];
+                if (c == '>' || c == '+' || c == '@') { ++p; break; }
+                if (c == '\n') { ++p; c = -1; continue; }
+                const char* nl = (const char*)memchr(buf + p, '\n', len - p);
+                const size_t end = nl ? (size_t)(nl - buf) : len;
+                seq.append(buf + p, end - p);
+                p = nl ? end + 1 : len;
+                if (seq.size() > 1 && seq.back() == '\r') seq.pop_back();
+                c = -1;
+            }
+        } else {
+            p = len;
         }
-        bool stop = false;
-        if (have && line[0] == '+') {
+        if (c == '>' || c == '@') last = c;
+        bool print = true, stop = c == -1;                    // the input ended inside or right after this record
+        if (c == '+') {
+            const char* nl = (const char*)memchr(buf + p, '\n', len - p);      // the rest of the '+' line
+            if (!nl) break;                                   // no quality string: kseq_read returns -2
+            p = (size_t)(nl - buf) + 1;
             size_t qual = 0;
-            have = next_line(&line, &ll);
-            while (have) {
-                qual += ll;
-                if (qual >= seq.size()) break;
-                have = next_line(&line, &ll);
+            while (p < len) {
+                const char* ql = (const char*)memchr(buf + p, '\n', len - p);
+                const size_t end = ql ? (size_t)(ql - buf) : len;
+                size_t l = end - p;
+                if (qual + l > 1 && l && buf[end - 1] == '\r') --l;
+                qual += l;
+                p = ql ? end + 1 : len;
+                if (!(qual < seq.size())) break;
             }
-            if (qual != seq.size()) stop = true;          // truncated or overlong quality: kseq_read returns -2
-            else {
-                have = next_line(&line, &ll);
-                while (have && !(ll && (line[0] == '>' || line[0] == '@'))) have = next_line(&line, &ll);
-            }
+            last = 0;
+            if (qual != seq.size()) break;                    // truncated or overlong quality: kseq_read returns -2
+            stop = false;
+            (void)print;
         }
-        if (stop) break;
-        for (char& c : seq) {
-            if (c >= 'a' && c <= 'z') c = (char)(c - 32);
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') c = 'A';
+        for (char& ch : seq) {
+            if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ch = 'A';
         }
         if (!seq.empty()) { int rc = add_record(q, name, seq, false); if (rc) return rc; }
+        if (stop) break;
     }
     return PM_OK;
 }

@@ -3,8 +3,9 @@
 `seqtk seq -A -U -C in | awk 'odd lines as is; even lines: gsub(/[^ACGT]/, "A")'`:
 FASTA or FASTQ in (multi-line allowed), one `>name` line (comment dropped) and
 one upper-case sequence line with every non-ACGT byte replaced by `A` out.
-seqtk is not available in the build container, so this mirror is pinned only
-by the awk half (tests/test_golden_cpu.py::test_fix_query_*); SURVEY.md 8f rank 4.
+seqtk is not available in the build container: its reader (kseq.h's kseq_read) is
+restated step by step in iter_records, the awk half is pinned by running awk
+(tests/test_golden_cpu.py::test_fix_query_*); SURVEY.md 8f rank 4.
 """
 import gzip
 import sys
@@ -16,27 +17,74 @@ def _open(path):
     return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
 
 
+_SPACE = b" \t\n\v\f\r"                                   # isspace(): what ends a record's name in kseq
+
+
 def iter_records(stream):
-    """kseq-style FASTA/FASTQ reader: yields (name, sequence bytes)"""
-    name, seq, in_qual, qual_left = None, [], False, 0
-    for raw in stream:
-        line = raw.rstrip(b"\r\n")
-        if in_qual:
-            qual_left -= len(line)
-            if qual_left <= 0:
-                in_qual = False
+    """FASTA/FASTQ records as kseq.h's kseq_read() delivers them to seqtk -- the steps of that function restated on a
+    byte string: yields (name, sequence bytes); a FASTQ record whose quality is truncated or overlong ends the input
+    (seqtk's read loop stops at kseq_read() < 0) and is not yielded"""
+    data = stream if isinstance(stream, (bytes, bytearray)) else stream.read()
+    n, p, last = len(data), 0, 0
+    while True:
+        if last == 0:                                      # jump to the next header byte, wherever in a line it stands
+            hits = [i for i in (data.find(b">", p), data.find(b"@", p)) if i >= 0]
+            if not hits:
+                return
+            p = min(hits) + 1
+        if p >= n:
+            return
+        e = p
+        while e < n and data[e] not in _SPACE:
+            e += 1
+        name, seq, c = data[p:e], bytearray(), -1
+        if e < n:
+            p = e + 1
+            if data[e] != 10:                              # the comment: to the end of the line
+                nl = data.find(b"\n", p)
+                p = n if nl < 0 else nl + 1
+            while p < n:                                   # sequence lines
+                c = data[p]
+                if c in b">+@":
+                    p += 1
+                    break
+                if c == 10:
+                    p, c = p + 1, -1
+                    continue
+                nl = data.find(b"\n", p)
+                end = n if nl < 0 else nl
+                seq += data[p:end]
+                p = n if nl < 0 else nl + 1
+                if len(seq) > 1 and seq[-1] == 13:
+                    del seq[-1]
+                c = -1
+        else:
+            p = n
+        if c in (62, 64):
+            last = c
+        if c != 43:                                        # FASTA record (or the input ended)
+            yield bytes(name), bytes(seq)
+            if c == -1:
+                return
             continue
-        if line[:1] in (b">", b"@"):
-            if name is not None:
-                yield name, b"".join(seq)
-            name, seq = line[1:].split(None, 1)[0] if line[1:].split() else b"", []
-        elif line[:1] == b"+" and name is not None:
-            qual_left = sum(len(s) for s in seq)
-            in_qual = qual_left > 0
-        elif name is not None:
-            seq.append(line)
-    if name is not None:
-        yield name, b"".join(seq)
+        nl = data.find(b"\n", p)                           # FASTQ: the rest of the '+' line, then the quality
+        if nl < 0:
+            return
+        p, qual = nl + 1, 0
+        while p < n:
+            nl = data.find(b"\n", p)
+            end = n if nl < 0 else nl
+            ln = end - p
+            if qual + ln > 1 and ln and data[end - 1] == 13:
+                ln -= 1
+            qual += ln
+            p = n if nl < 0 else nl + 1
+            if not qual < len(seq):
+                break
+        last = 0
+        if qual != len(seq):
+            return
+        yield bytes(name), bytes(seq)
 
 
 def fix_stream(stream, out, base_to_replace=b"A"):

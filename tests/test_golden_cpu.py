@@ -1245,3 +1245,57 @@ def test_merge_over_pieces_of_a_query_file_keeps_the_whole_files_dict_semantics(
         assert again.emit() == want
     with pytest.raises(pm.PMError):
         m.add("b0", ixs[0], recs[0][:0], piece=99)
+
+
+def test_native_fix_query_and_the_mirror_agree_on_random_ill_formed_input():
+    """pm_queries_parse_raw(normalise = 1) and phylign_amd/fix_query.py both restate kseq_read() step by step; on random
+    FASTA / FASTQ with the things real files do -- CRLF, empty lines, comments after blanks or TABs, junk ahead of the
+    first record, '@' and '>' as quality values, a header byte in the middle of a line, quality blocks that are too
+    short or too long (the reader stops there, like seqtk), missing final newlines -- they deliver the same records
+    (the parser drops records without sequence, which cobs ignores, and refuses sequences shorter than k)"""
+    import io
+    from phylign_amd import _lib as pm
+    from phylign_amd import fix_query as FQ
+    rng = np.random.default_rng(33)
+    alpha = list(b"ACGTacgtNnRYKMSWryu-.*")
+    agree = 0
+    for it in range(700):
+        parts = []
+        if rng.random() < 0.2:
+            parts.append(bytes(rng.choice(list(b"ACGT\n >@+x"), size=int(rng.integers(0, 30))).astype(np.uint8)))
+        for i in range(int(rng.integers(0, 8))):
+            n = int(rng.integers(0, 120)) if rng.random() < 0.2 else int(rng.integers(31, 200))
+            seq = bytes(rng.choice(alpha, size=n).astype(np.uint8))
+            width = int(rng.integers(10, 90))
+            nl = b"\r\n" if rng.random() < 0.15 else b"\n"
+            lines = nl.join(seq[j:j + width] for j in range(0, n, width)) if n else b""
+            if rng.random() < 0.1:
+                lines = lines.replace(nl, nl + nl, 1)
+            hdr = [b"r%d" % i, b"r%d comment x" % i, b"r%d\tdesc" % i, b"", b" lead", b"r%d " % i, b"r%d\x0bv" % i][int(rng.integers(0, 7))]
+            if rng.random() < 0.4:
+                ql = n if rng.random() < 0.7 else max(0, n + int(rng.integers(-5, 6)))
+                qual = bytes(rng.integers(33, 75, size=ql).astype(np.uint8))
+                if rng.random() < 0.3 and ql > 2:
+                    qual = b"@" + qual[1:]
+                if rng.random() < 0.2 and ql > 2:
+                    qual = b">" + qual[1:]
+                qlines = nl.join(qual[j:j + width] for j in range(0, ql, width))
+                parts.append(b"@" + hdr + nl + lines + nl + b"+" + (hdr if rng.random() < 0.3 else b"") + nl + qlines + (nl if rng.random() < 0.9 else b""))
+            else:
+                parts.append(b">" + hdr + nl + lines + (nl if rng.random() < 0.9 else b""))
+        raw = b"".join(parts)
+        out = io.BytesIO()
+        FQ.fix_stream(io.BytesIO(raw), out)
+        recs = out.getvalue().split(b"\n")
+        pairs = [(recs[i], recs[i + 1]) for i in range(0, len(recs) - 1, 2)]
+        want = b"".join(h + b"\n" + s_ + b"\n" for h, s_ in pairs if s_)           # records without sequence are dropped
+        if any(0 < len(s_) < 31 for _, s_ in pairs):
+            with pytest.raises(pm.PMError):
+                pm.Queries(raw, term_size=31, normalise=True)
+            continue
+        assert pm.Queries(raw, term_size=31, normalise=True).fasta() == want, (it, raw[:300])
+        agree += 1
+    assert agree > 400
+    # kseq's jump to the next header byte does not care where in a line it stands
+    raw = b"junk ACGT>r1 c\n" + b"ACGT" * 10 + b"\n"
+    assert pm.Queries(raw, term_size=31, normalise=True).fasta() == b">r1\n" + b"ACGT" * 10 + b"\n"

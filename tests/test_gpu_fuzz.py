@@ -66,6 +66,21 @@ def test_random_case_text_identical(pm, oracle, seed):
     assert pm.query_text(ix, fasta, thr) == exp
     n = int(rng.choice([1, 2, 5, 100]))
     assert pm.query_text(ix, fasta, thr, nb_best_hits=n).decode() == P.filter_text(exp.decode(), n)
+    # the same reads as a file the record rules have to work for: wrapped sequence lines, empty lines, ';' headers, a
+    # first record without header line, a header without sequence, no final newline
+    lines = []
+    for i, (h, sq) in enumerate(queries):
+        if not (i == 0 and rng.random() < 0.3):
+            lines.append((";" if rng.random() < 0.2 else ">") + h)
+        w = int(rng.integers(7, 80))
+        for j in range(0, len(sq), w):
+            lines.append(sq[j:j + w])
+            if rng.random() < 0.1:
+                lines.append("")
+        if rng.random() < 0.15:
+            lines.append(">no_sequence_%d" % i)
+    odd = ("\n".join(lines) + ("\n" if rng.random() < 0.8 else "")).encode()
+    assert pm.query_text(ix, odd, thr) == oracle.query_file(index, odd, thr)
 
 
 @pytest.mark.parametrize("seed", _seeds(24))

@@ -138,10 +138,13 @@ def test_match_to_filter_dropin(pm, oracle, tmp_path):
     assert all(len(recs[i].split(" ")[1].split(",")) >= 3 for i in range(0, 24, 2))
 
 
-def _stage_fixture(oracle, tmp_path, n_batches=5):
+def _stage_fixture(oracle, tmp_path, n_batches=5, repeated_names=False):
     """a small cobs/ directory with xz indexes, a batches file, the sizes table and a query FASTA"""
     rng = np.random.default_rng(77)
     queries = [(f"q{i} c", rand_seq(rng, 150)) for i in range(20)]
+    if repeated_names:                                  # the mates of read pairs in concatenated files: one query each
+        for i, j in ((9, 2), (16, 2), (19, 11)):
+            queries[i] = (queries[j][0], queries[i][1])
     cobs = tmp_path / "cobs"
     cobs.mkdir()
     shapes = [(195, 5000), (176, 9000), (664, 6000), (4000, 3000), (30, 4000)][:n_batches]
@@ -222,13 +225,14 @@ def test_match_stage_searches_resident_batches_with_fused_launches(pm, oracle, t
     json.dumps(report2)
 
 
-@pytest.mark.parametrize("ranks", [1, 2])
-def test_match_stage_searches_a_large_query_file_in_chunks(pm, oracle, tmp_path, ranks):
+@pytest.mark.parametrize("ranks,repeated", [(1, False), (2, False), (2, True)])
+def test_match_stage_searches_a_large_query_file_in_chunks(pm, oracle, tmp_path, ranks, repeated):
     """--query-chunk: 20 reads in chunks of 7 (3 chunks) against batches that stream through a tiny HBM budget -- every
-    batch's file is written piece by piece, the 04_filter FASTA chunk by chunk, and both equal the one-piece run's
-    (one rank, and two ranks with the per-chunk gather over gloo)"""
+    batch's file is written piece by piece, the ONE 04_filter merge grows chunk by chunk, and files and FASTA equal the
+    one-piece run's (one rank, and two ranks with the gather over gloo; also with read names that repeat across the
+    chunks: one query each, as in the consumer's dict)"""
     import json
-    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path, repeated_names=repeated)
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable]
     if ranks == 2:

@@ -308,8 +308,8 @@ def test_configs4_5_one_rank_shard_of_the_full_collection(pm, oracle, tmp_path):
     src = MS.ResidentSource({s.batch: ixs[i] for i, s in enumerate(sub)})
     report, merge = MS.run_stage(pm, names, list(range(len(names))), src, q, "Q", str(tmp_path / "03_match"), 0.7, 100,
                                  want_merge=True)
-    # 38 resident batches: two pipelined halves, each a fused search (one launch per row-width class)
-    assert report["groups"] == 2 and report["scan_launches"] <= 8 and report["queries"] == nq
+    # 38 resident batches: four pipelined quarters, each a fused search (one launch per row-width class)
+    assert report["groups"] == 4 and report["scan_launches"] <= 16 and report["queries"] == nq
     out_fa = merge.emit().decode()
     # sampled queries: planted ones (hits in one batch) and unplanted ones
     planted_q = list(range(0, nq, 2500))[:6]

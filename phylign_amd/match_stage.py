@@ -277,7 +277,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             return group
 
     deflaters = ThreadPoolExecutor(max_workers=max(2, min(16, len(os.sched_getaffinity(0)))))
-    workers = ThreadPoolExecutor(max_workers=max(2, min(6, len(os.sched_getaffinity(0)) // 2)))
+    workers = ThreadPoolExecutor(max_workers=int(os.environ.get("PM_STAGE_WORKERS", "0")) or max(2, min(6, len(os.sched_getaffinity(0)) // 2)))
     group_rows = []
 
     def finish(group, ci, res, t_queued):

@@ -1299,3 +1299,53 @@ def test_native_fix_query_and_the_mirror_agree_on_random_ill_formed_input():
     # kseq's jump to the next header byte does not care where in a line it stands
     raw = b"junk ACGT>r1 c\n" + b"ACGT" * 10 + b"\n"
     assert pm.Queries(raw, term_size=31, normalise=True).fasta() == b">r1\n" + b"ACGT" * 10 + b"\n"
+
+
+def test_merge_is_extended_while_other_threads_add(tmp_path):
+    """what the stage does: one thread parses the next pieces of the query file and extends the merge while workers
+    add the records of pieces that are already there (ctypes calls run without the GIL; run under ThreadSanitizer by
+    tools/asan_cpu_tests.sh thread) -- the result is the one-piece merge's"""
+    import threading
+    from phylign_amd import _lib as pm
+    from phylign_amd.match_stage import split_prepared_fasta
+    rng = np.random.default_rng(55)
+    nq = 70000
+    fasta = "".join(f">r{i % 60000}\n{'ACGT' * 8}A\n" for i in range(nq)).encode()       # 10 000 names repeat far away
+    ix = pm.Index.from_names([f"{d:03x}_R{d}" for d in range(64)])
+    recs = []
+    for b in range(4):
+        hq = np.sort(rng.choice(nq, size=20000, replace=False)).astype(np.uint32)
+        r = np.zeros(len(hq), dtype=pm.HIT_DTYPE)
+        r["query"] = hq; r["doc"] = rng.integers(0, 64, len(r)); r["score"] = rng.integers(1, 9, len(r))
+        recs.append(pm.sort_hits(r))
+    whole = pm.Merge(pm.Queries(fasta), 3)
+    for b in range(4):
+        whole.add(f"b{b}", ix, recs[b], slot=0)
+    want = whole.emit()
+    pieces = [pm.Queries(p) for p in split_prepared_fasta(fasta, 9000)]
+    base = np.cumsum([0] + [p.count()[0] for p in pieces])
+    m = pm.Merge(pieces[0], 3)
+    ready = [threading.Event() for _ in pieces]
+    ready[0].set()
+    errs = []
+
+    def extender():
+        for ci in range(1, len(pieces)):
+            m.extend(pieces[ci])
+            ready[ci].set()
+
+    def adder(b):
+        try:
+            for ci in range(len(pieces)):
+                ready[ci].wait()
+                part = recs[b][(recs[b]["query"] >= base[ci]) & (recs[b]["query"] < base[ci + 1])].copy()
+                part["query"] -= np.uint32(base[ci])
+                m.add(f"b{b}", ix, part, slot=0, piece=ci)
+        except Exception as e:                              # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=extender)] + [threading.Thread(target=adder, args=(b,)) for b in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and m.emit() == want

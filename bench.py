@@ -3,7 +3,7 @@
 661k-shaped synthetic index set, with the HBM roofline of the scan kernel and
 the CPU (oracle "port") baseline timed beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--clustered-multi", action="store_true",
                     help="run the clustered variant with N > 1 too (it ships ~0.5 GB of records per step to rank 0; "
                          "by default it is a single-GPU figure)")
+    ap.add_argument("--no-replicas", action="store_true",
+                    help="N > 1: whole batches only (by default a few small batches are resident on two ranks that share their "
+                         "queries, which levels the ranks' scan work)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queueing the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=24.0, help="timed CPU work of the baseline (2 partitions x 3 runs)")
@@ -190,9 +193,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from phylign_amd import launch
+    if launch.wants_self_launch(args.gpus):
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (torch is not even imported yet), so it
+        # starts N fresh ranks of the same command line, relays their output (rank 0 prints the JSON line) and their status
+        sys.exit(launch.self_launch_script(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     def log(msg):
@@ -210,6 +216,8 @@ def main():
     # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1: functional check of the N>1 code path
     # with several ranks on ONE GPU (RCCL refuses duplicate devices); never a reported number
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > 1 and not os.environ.get("BENCH_SHARE_GPU") and 1 < torch.cuda.device_count() < world:
+        sys.exit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPUs are visible (RCCL needs one device per rank)")
     if os.environ.get("BENCH_SHARE_GPU") or local_rank >= torch.cuda.device_count():
         # functional check on one GPU, or a launcher that already narrowed the visible devices per rank
         local_rank = local_rank % torch.cuda.device_count()
@@ -235,7 +243,12 @@ def main():
     if args.rows_divisor > 1:
         shapes = W.scale_shapes(shapes, args.rows_divisor)
     nparts = args.emulate_world if (args.emulate_world and world == 1) else world
-    parts = W.assign_batches(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))
+    # static batch -> rank map; a few small batches are resident on two ranks that share their queries (assign_parts)
+    if args.no_replicas:
+        pparts = [[(p_, 0, W.PART_DEN) for p_ in part] for part in W.assign_batches(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))]
+    else:
+        pparts = W.assign_parts(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))
+    parts = [[p_ for p_, _, _ in part] for part in pparts]
     base = 0
     bases = []
     for r in range(nparts):
@@ -243,6 +256,8 @@ def main():
         base += len(parts[r])
     part_id = args.emulate_rank if nparts != world else rank
     mine = parts[part_id]
+    my_shares = [None if hi - lo == W.PART_DEN else (lo, hi, W.PART_DEN) for _, lo, hi in pparts[part_id]]
+    shared = sorted({p_ for part in pparts for p_, lo, hi in part if hi - lo != W.PART_DEN})
 
     # ---- inputs resident in HBM before the timed region -------------------
     t0 = time.time()
@@ -282,18 +297,21 @@ def main():
     kept = []        # results whose pinned records are still referenced (freed at the end)
     phase = {"queue": 0.0, "wait": 0.0, "host": 0.0, "gather": 0.0}
 
-    def narrow_lines(infs):
-        """128-byte lines one k-mer touches in the batches of the mixed-width launch (rows of at most 256 bytes)"""
-        return sum(max(1, int(i.stride) // 128) for i in infs if i.stride <= 256)
+    def narrow_lines(infs, shares=None):
+        """128-byte lines one k-mer touches in the batches of the mixed-width launch (rows of at most 256 bytes); a batch
+        searched with a share of the queries counts by that share"""
+        w = [1.0 if sh is None else (sh[1] - sh[0]) / sh[2] for sh in (shares or [None] * len(infs))]
+        return sum(max(1, int(i.stride) // 128) * w_ for i, w_ in zip(infs, w) if i.stride <= 256)
 
     # what the step functions below run on; swapped for the l31 and full_shard legs
     cur = {"indexes": indexes, "q": q, "n_terms": n_terms, "rowsum": sum(s.row_bytes for s in shapes),
            "slot_base": bases[part_id], "terms_per_q": terms_per_q, "tag": args.workload,
-           "narrow_lines_per_kmer": narrow_lines(infos)}
+           "narrow_lines_per_kmer": narrow_lines(infos, my_shares), "shares": my_shares}
 
     def queue_step():
         t_a = time.perf_counter()
-        res = pm.search_async(cur["indexes"], cur["q"], args.threshold, slot_base=cur["slot_base"], nb_best_hits=args.nb_best_hits)
+        res = pm.search_async(cur["indexes"], cur["q"], args.threshold, slot_base=cur["slot_base"], nb_best_hits=args.nb_best_hits,
+                              parts=cur.get("shares"))
         phase["queue"] += time.perf_counter() - t_a
         return res
 
@@ -376,20 +394,24 @@ def main():
         sync()
         elapsed = time.perf_counter() - t_start
         rank_elapsed = [elapsed]
+        rank_phase = [[phase["queue"], phase["wait"], phase["host"], phase["gather"], packed.waited_s]]
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            t = torch.tensor([elapsed] + rank_phase[0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)
-            rank_elapsed = [float(x.item()) for x in every]
+            rank_elapsed = [float(x[0].item()) for x in every]
+            rank_phase = [[float(v) for v in x[1:].tolist()] for x in every]
             elapsed = max(rank_elapsed)                       # the step of the job is the slowest rank's
-        return {"elapsed": elapsed, "rank_elapsed": rank_elapsed, "groups": groups, "phase": dict(phase), "hits": last.get("hits"),
+        packed.waited_s = 0.0
+        return {"elapsed": elapsed, "rank_elapsed": rank_elapsed, "rank_phase": rank_phase, "groups": groups, "phase": dict(phase), "hits": last.get("hits"),
                 "n_hits": last.get("n_hits"), "stats": last["stats"]}
 
     def fetched_pass(bound):
         """one untimed search with the in-kernel counter on: algorithmic bytes really gathered, per kernel"""
         pm.set_option("threshold_bound", 1 if bound else 0)
         pm.set_option("count_fetched", 1)
-        res = pm.search(cur["indexes"], cur["q"], args.threshold, slot_base=cur["slot_base"], nb_best_hits=args.nb_best_hits)
+        res = pm.search(cur["indexes"], cur["q"], args.threshold, slot_base=cur["slot_base"], nb_best_hits=args.nb_best_hits,
+                        parts=cur.get("shares"))
         out = {L["kernel"]: (L["fetched_bytes"], L["algorithmic_bytes"]) for L in res.launches()}
         res.free()
         pm.set_option("count_fetched", 0)
@@ -504,6 +526,11 @@ def main():
     # GPU that holds its matrices and its own time for the K steps
     participants = {"backend": backend if world > 1 else None, "rccl_ranks": None,
                     "rank_ms_per_step": [e / args.steps * 1e3 for e in run_head["rank_elapsed"]],
+                    # host time per step and rank: queueing the launches, waiting for the GPU, ordering the runs on the device,
+                    # the gather of hit records (root: until every rank's records are on its host; others: queueing the send),
+                    # and waiting for a send buffer to come free again (double-buffered: ~0)
+                    "rank_host_ms": [dict(zip(("queue_launches", "wait_for_gpu", "run_order", "hit_gather", "send_buffer_wait"),
+                                              [round(v / args.steps * 1e3, 4) for v in ph_])) for ph_ in run_head["rank_phase"]],
                     "rank_devices": [indexes[0].device if indexes else local_rank]}
     if world > 1:
         ddev = "cuda" if backend == "nccl" else "cpu"
@@ -600,7 +627,7 @@ def main():
                 f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
             saved = dict(cur)
             cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fshapes), "slot_base": fbases[rank],
-                        "tag": f"full/{world}", "narrow_lines_per_kmer": narrow_lines(finfos)})
+                        "tag": f"full/{world}", "narrow_lines_per_kmer": narrow_lines(finfos), "shares": None})
             fc_steps = max(3, min(args.steps, 10))
             full_collection = {"workload": f"all {len(fshapes)} batches of batches_full.txt ({sum(sh.index_bytes for sh in fshapes) / 1e12:.2f} TB of "
                                            f"signatures, {cur['rowsum']} row bytes per k-mer) sharded over {world} ranks, {nq} x {args.qlen} bp queries, "
@@ -702,7 +729,7 @@ def main():
             log(f"[bench] full_shard: {len(indexes)} batches, {sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
             saved = dict(cur)
             cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fsub), "slot_base": 0,
-                        "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_kmer": narrow_lines(finfos)})
+                        "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_kmer": narrow_lines(finfos), "shares": None})
             fs_steps = max(3, min(args.steps, 10))
             full_shard = {"workload": f"rank {args.full_shard_rank} of {args.full_shard_world} of batches_full.txt (305 batches, 1.06 TB, 82 741 row "
                                       f"bytes per k-mer): {len(fsub)} batches, {sum(sh.index_bytes for sh in fsub) / 1e9:.1f} GB on disk, "
@@ -758,6 +785,9 @@ def main():
                    "num_hashes": 1, "threshold": args.threshold, "nb_best_hits": args.nb_best_hits,
                    "rows_divisor": args.rows_divisor,
                    "sharding": f"{world} rank(s), static LPT batch assignment, one gather of hit records",
+                   "batches_on_two_ranks": [{"batch": shapes[p_].batch, "index_GB": round(shapes[p_].index_bytes / 1e9, 3),
+                                             "query_shares": {str(r_): [lo, hi, W.PART_DEN] for r_, part in enumerate(pparts)
+                                                              for q_, lo, hi in part if q_ == p_}} for p_ in shared],
                    "pipelined_steps": not args.no_pipeline},
         "scan_mode": (head + (": every signature row of every k-mer is gathered, like `cobs query` does -- independent "
                               "of the data; the product default (threshold_bound) is reported beside it"

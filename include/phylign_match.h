@@ -14,6 +14,9 @@
  * the boundary.  One process drives one GPU.  There is NO CPU fallback: without
  * a visible gfx950 device pm_init() fails and every compute entry point
  * returns PM_ENODEV.
+ *
+ * Measurement and test aids (synthetic 661k-shaped indexes, planted hits, the
+ * gather probe) are NOT here: include/phylign_match_bench.h, libphylign_bench.so.
  */
 #ifndef PHYLIGN_MATCH_H
 #define PHYLIGN_MATCH_H
@@ -21,6 +24,10 @@
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* the library is built with hidden visibility: exactly the entry points declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
 #endif
 
 #define PM_OK        0
@@ -140,32 +147,21 @@ int  pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out);
 int  pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out);
 /* header + document names only (no matrix): for the rank that formats text */
 int  pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out);
-/* 661k-shaped synthetic index generated in HBM; header_only!=0
- * creates just the names table "%05x_SYN%07u". */
-int  pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signature_size,
-                    uint32_t num_hashes, uint32_t term_size, uint64_t seed,
-                    int layout, int header_only, pm_index_t** out);
 /* names-only handle from `n_docs` newline-terminated names (rank 0 formats and
  * merges batches it does not hold) */
 int  pm_index_from_names(const char* names, size_t len, uint32_t n_docs, uint32_t term_size, pm_index_t** out);
 /* releases the HBM matrix, keeps header and names (streaming one batch after another) */
 int  pm_index_drop_matrix(pm_index_t* idx);
-/* sets bit (rows[i], docs[i]) for i<n: planted hits for parity runs */
-int  pm_index_plant(pm_index_t* idx, const uint64_t* rows, const uint32_t* docs, size_t n);
-/* Measurement / test aid: synthetic "related batch" content.  Makes this index the HOME
- * batch of queries q_first, q_first + q_step, ...: about half of its 32-document clusters
- * match each of those queries at a k-mer fraction between 0.6 and 1.0 (k_plant_cluster),
- * the shape real phylogenetic batches have for reads of their own species. */
-int  pm_index_plant_cluster(pm_index_t* idx, pm_queries_t* q, uint32_t q_first, uint32_t q_step, uint64_t seed);
+/* An index made in place instead of read from a file: the header fields, `n_docs` newline-terminated names and a ZEROED
+ * signature matrix in HBM (header_only != 0: names only).  Code that builds signatures on the device fills the matrix
+ * through pm_index_matrix_device. */
+int  pm_index_create(uint32_t term_size, uint32_t canonicalize, uint64_t signature_size, uint32_t num_hashes,
+                     const char* names, size_t names_len, uint32_t n_docs, int layout, int header_only, pm_index_t** out);
+/* the resident matrix of a classic index, for code that shares the device with the library: row r starts at
+ * *dptr + r * *stride, document d is bit d % 8 of byte d / 8 (fails for header-only handles and compact indexes) */
+int  pm_index_matrix_device(const pm_index_t* idx, void** dptr, uint64_t* stride);
 /* copies n rows starting at row0 (row_bytes each, file layout) back to the host (checks) */
 int  pm_index_read_rows(const pm_index_t* idx, uint64_t row0, uint64_t n, void* out);
-/* Measurement aid, not part of the matching path: times a pure random-row
- * gather over this index with k_scan's access pattern (n_groups row-cooperating
- * lane groups x lookups_per_group rows each, no counting); *ms = hipEvent time,
- * *bytes = rows fetched x row_bytes.  Gives the memory-system ceiling the scan
- * kernel is compared with in DESIGN.md. */
-int  pm_index_probe_gather(const pm_index_t* idx, uint64_t n_groups, uint64_t lookups_per_group,
-                           double* ms, uint64_t* bytes);
 int  pm_index_info(const pm_index_t* idx, pm_index_info_t* info);
 /* GPU that holds the matrix (-1: header-only handle).  HIP's current device is a
  * per-thread setting; every entry point binds the calling thread to the device of
@@ -224,6 +220,17 @@ int  pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
  * or freed) from two threads at the same time -- the handle caches its hashes and per-query thresholds. */
 int  pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                      double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out);
+/* The same with a PART of the query set per index: a batch that is resident on several GPUs is searched by each of them
+ * with a share of the queries (the static batch -> GPU map evens out the ranks' scan work that way).  In
+ * every counter-width class of the query set (queries of < 8, < 128, < 1 024, < 2^16, < 2^20, < 2^24 k-mers) with n
+ * queries in file order, index i sees those at positions floor(lo * n / den) ... floor(hi * n / den) - 1; den == 0 (or
+ * parts == NULL): all of them.  Which queries a part holds depends on the query set alone, so the parts [0, a), [a, b),
+ * ..., [z, den) of one index -- searched anywhere -- cover every query exactly once, and the union of their records is
+ * the record set of the whole search. */
+typedef struct { uint32_t lo, hi, den; } pm_qpart_t;
+int  pm_search_async_parts(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+                           double threshold, uint32_t nb_best_hits, uint32_t slot_base,
+                           const pm_qpart_t* parts, pm_result_t** out);
 int  pm_result_wait(pm_result_t* r);
 int  pm_result_stats(const pm_result_t* r, pm_stats_t* st);
 /* the scan-kernel launches of the search (one per row-width class x counter-width
@@ -343,6 +350,9 @@ int  pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes);
 int  pm_merge_emit_file_piece(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes);
 void pm_merge_free(pm_merge_t* m);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

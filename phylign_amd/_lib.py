@@ -63,13 +63,11 @@ SYMBOLS = [
     ("pm_index_load_fd", C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(_P)]),
     ("pm_index_load_mem", C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     ("pm_index_load_header_mem", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
-    ("pm_index_synth", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("pm_index_create", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("pm_index_matrix_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("pm_index_from_names", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("pm_index_drop_matrix", C.c_int, [_P]),
-    ("pm_index_plant", C.c_int, [_P, _P, _P, C.c_size_t]),
-    ("pm_index_plant_cluster", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("pm_index_read_rows", C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
-    ("pm_index_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("pm_index_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
     ("pm_index_device", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("pm_index_doc_name", _P, [_P, C.c_uint32, C.POINTER(C.c_size_t)]),
@@ -85,6 +83,7 @@ SYMBOLS = [
     ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
     ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("pm_search_async", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("pm_search_async_parts", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, _P, C.POINTER(_P)]),
     ("pm_result_wait", C.c_int, [_P]),
     ("pm_result_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("pm_result_launches", C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -212,10 +211,24 @@ class Index:
     @classmethod
     def synth(cls, batch_id, n_docs, signature_size, num_hashes=1, term_size=31, seed=661,
               layout=PM_LAYOUT_AUTO, header_only=False):
+        """measurement / test aid (libphylign_bench.so): a 661k-shaped synthetic index generated in HBM"""
+        from . import bench_aids
+        return cls(bench_aids.index_synth(batch_id, n_docs, signature_size, num_hashes, term_size, seed, layout, header_only))
+
+    @classmethod
+    def create(cls, names, signature_size, num_hashes=1, term_size=31, canonicalize=1, layout=PM_LAYOUT_AUTO, header_only=False):
+        """an index made in place: header + names + a zeroed matrix in HBM (pm_index_create)"""
+        blob = "".join(n + "\n" for n in names).encode()
         h = _P()
-        _chk(load().pm_index_synth(batch_id, n_docs, signature_size, num_hashes, term_size, seed,
-                                   layout, int(header_only), C.byref(h)))
+        _chk(load().pm_index_create(term_size, canonicalize, signature_size, num_hashes, blob, len(blob), len(names), layout,
+                                    int(header_only), C.byref(h)))
         return cls(h)
+
+    def matrix_device(self):
+        """(device address, stride) of the resident matrix"""
+        p, st = _P(), C.c_uint64()
+        _chk(load().pm_index_matrix_device(self._h, C.byref(p), C.byref(st)))
+        return p.value, st.value
 
     @classmethod
     def from_names(cls, names, term_size=31):
@@ -231,25 +244,25 @@ class Index:
         _chk(load().pm_index_drop_matrix(self._h))
 
     def plant(self, rows, docs):
-        rows = np.ascontiguousarray(rows, dtype=np.uint64)
-        docs = np.ascontiguousarray(docs, dtype=np.uint32)
-        assert rows.size == docs.size
-        _chk(load().pm_index_plant(self._h, rows.ctypes.data, docs.ctypes.data, rows.size))
+        """measurement / test aid (libphylign_bench.so): sets bit (rows[i], docs[i])"""
+        from . import bench_aids
+        bench_aids.index_plant(self._h, rows, docs)
 
     def plant_cluster(self, queries, q_first, q_step, seed=97):
-        """makes this index the home batch of queries q_first, q_first + q_step, ... (see the header)"""
-        _chk(load().pm_index_plant_cluster(self._h, queries._h, q_first, q_step, seed))
+        """measurement / test aid (libphylign_bench.so): makes this index the home batch of queries q_first,
+        q_first + q_step, ... (see include/phylign_match_bench.h)"""
+        from . import bench_aids
+        bench_aids.index_plant_cluster(self, queries, q_first, q_step, seed)
 
     def read_rows(self, row0, n):
         out = np.zeros((n, self.info.row_bytes), dtype=np.uint8)
         _chk(load().pm_index_read_rows(self._h, row0, n, out.ctypes.data))
         return out
 
-    def probe_gather(self, n_groups, lookups_per_group):
-        """(ms, algorithmic bytes) of a pure random-row gather with k_scan's access pattern"""
-        ms, nb = C.c_double(), C.c_uint64()
-        _chk(load().pm_index_probe_gather(self._h, n_groups, lookups_per_group, C.byref(ms), C.byref(nb)))
-        return ms.value, nb.value
+    def probe_gather(self, n_groups, lookups_per_group, **kw):
+        """measurement aid (libphylign_bench.so): (ms, algorithmic bytes) of a pure random-row gather with k_scan's pattern"""
+        from . import bench_aids
+        return bench_aids.probe_gather(self, n_groups, lookups_per_group, **kw)
 
     @property
     def info(self):
@@ -354,6 +367,8 @@ class Queries:
 
     def free(self):
         if self._h:
+            for h in self.__dict__.pop("_aid_hashes", {}).values():      # device copies the measurement aids made
+                h.free()
             load().pm_queries_free(self._h)
             self._h = None
 
@@ -467,19 +482,33 @@ class Slice:
             pass
 
 
-def search(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hits=0) -> Result:
+def search(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hits=0, parts=None) -> Result:
     """nb_best_hits > 0: per (query, index) keep the n best documents + ties (on the GPU)"""
+    if parts is not None:
+        res = search_async(indexes, queries, threshold, slot_base, nb_best_hits, parts)
+        res.wait()
+        return res
     arr = (_P * len(indexes))(*[ix._h for ix in indexes])
     h = _P()
     _chk(load().pm_search(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
     return Result(h)
 
 
-def search_async(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hits=0) -> Result:
-    """search() that returns once the kernels are queued; Result.wait() / any getter blocks"""
+def search_async(indexes, queries: Queries, threshold: float, slot_base=0, nb_best_hits=0, parts=None) -> Result:
+    """search() that returns once the kernels are queued; Result.wait() / any getter blocks.
+    parts: per index None (all queries) or (lo, hi, den): the share of the queries this process searches the index
+    with (pm_search_async_parts: a batch resident on several ranks)"""
     arr = (_P * len(indexes))(*[ix._h for ix in indexes])
     h = _P()
-    _chk(load().pm_search_async(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
+    if parts is None or all(p is None for p in parts):
+        _chk(load().pm_search_async(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, C.byref(h)))
+        return Result(h)
+    assert len(parts) == len(indexes)
+    pa = np.zeros((len(indexes), 3), dtype=np.uint32)
+    for i, p_ in enumerate(parts):
+        if p_ is not None:
+            pa[i] = p_
+    _chk(load().pm_search_async_parts(arr, len(indexes), queries._h, threshold, nb_best_hits, slot_base, pa.ctypes.data, C.byref(h)))
     return Result(h)
 
 

@@ -129,6 +129,7 @@ struct pm_queries {
     std::vector<QDesc> qd;
     // plane classes: queries ordered by class, ranges per class
     std::vector<uint32_t> qmap;
+    std::vector<uint64_t> term_prefix;      // k-mers ahead of every position of qmap (n_queries + 1; built by the first search)
     std::vector<uint32_t> blkq;             // 8-slot block -> query
     bool on_device = false;
     uint32_t class_begin[kNumClasses + 1] = {};

@@ -496,84 +496,35 @@ extern "C" int pm_index_load_header_mem(const void* buf, size_t len, pm_index_t*
     return load_from_reader(rd, 0, PM_LAYOUT_COMPACT, true, out);
 }
 
-static uint64_t host_splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ULL;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
-    return x ^ (x >> 31);
-}
-
-extern "C" int pm_index_synth(uint32_t batch_id, uint32_t n_docs, uint64_t signature_size,
-                              uint32_t num_hashes, uint32_t term_size, uint64_t seed,
-                              int layout, int header_only, pm_index_t** out) {
-    if (!out || n_docs == 0 || signature_size == 0 || num_hashes == 0 || term_size == 0)
-        return fail(PM_EINVAL, "bad synthetic index shape");
+// An index made in place instead of read from a file: header fields + document names + a ZEROED matrix in HBM (or, with
+// header_only, names only).  Whoever builds signatures on the device fills the matrix through pm_index_matrix_device.
+extern "C" int pm_index_create(uint32_t term_size, uint32_t canonicalize, uint64_t signature_size, uint32_t num_hashes,
+                               const char* names, size_t names_len, uint32_t n_docs, int layout, int header_only,
+                               pm_index_t** out) {
+    if (!out || n_docs == 0 || signature_size == 0 || num_hashes == 0 || term_size == 0 || (!names && names_len))
+        return fail(PM_EINVAL, "bad index shape");
     if (!header_only) NEED_DEV();
-    pm_index* ix = new pm_index();
+    pm_index_t* named = nullptr;
+    { int rc = pm_index_from_names(names, names_len, n_docs, term_size, &named); if (rc) return rc; }
     ParsedHeader h;
-    h.version = 1; h.term_size = term_size; h.canon = 1; h.sig = signature_size; h.nh = num_hashes;
+    h.version = 1; h.term_size = term_size; h.canon = canonicalize ? 1 : 0; h.sig = signature_size; h.nh = num_hashes;
     h.n_docs = n_docs; h.layout = 0;
-    // names "<5 hex>_SYN<batch>D<doc>": a pseudo-random sorting prefix, one underscore
-    const uint64_t kb = host_splitmix64(seed ^ ((uint64_t)batch_id * 0xD1B54A32D192ED03ULL));
-    ix->name_off.resize((size_t)n_docs + 1);
-    char nm[64];
-    for (uint32_t d = 0; d < n_docs; ++d) {
-        int l = snprintf(nm, sizeof nm, "%05x_SYN%03uD%07u",
-                         (unsigned)(host_splitmix64(kb ^ (0xA5A5A5A5ull + d)) & 0xFFFFF), batch_id, d);
-        ix->name_off[d] = ix->names_blob.size();
-        ix->names_blob.append(nm, (size_t)l);
-        ix->names_blob.push_back('\0');
-    }
-    ix->name_off[n_docs] = ix->names_blob.size();
-    int rc = finish_index_shape(ix, h, layout, !header_only);
-    if (rc) { delete ix; return rc; }
+    int rc = finish_index_shape(named, h, layout, !header_only);
+    if (rc) { pm_index_free(named); return rc; }
     if (!header_only) {
-        hipError_t e = launch_synth(ix->d_matrix, ix->info.stride, signature_size, n_docs, seed, batch_id, g_ctx.stream);
+        hipError_t e = hipMemsetAsync(named->d_matrix, 0, named->info.device_bytes, g_ctx.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-        if (e != hipSuccess) { pm_index_free(ix); return fail(PM_EHIP, "synthetic generator: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { pm_index_free(named); return fail(PM_EHIP, "clearing the new matrix: %s", hipGetErrorString(e)); }
     }
-    *out = ix;
+    *out = named;
     return PM_OK;
 }
-
-extern "C" int pm_index_plant(pm_index_t* ix, const uint64_t* rows, const uint32_t* docs, size_t n) {
-    NEED_DEV();
-    if (!ix || !ix->d_matrix) return fail(PM_EINVAL, "index has no matrix (planting works on classic indexes)");
-    if (n == 0) return PM_OK;
-    for (size_t i = 0; i < n; ++i)
-        if (rows[i] >= ix->info.signature_size || docs[i] >= ix->info.n_docs)
-            return fail(PM_EINVAL, "plant %zu out of range", i);
-    uint64_t* dr = nullptr; uint32_t* dd = nullptr;
-    HIPCHK(hipMalloc((void**)&dr, n * 8));
-    hipError_t e = hipMalloc((void**)&dd, n * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(dr, rows, n * 8, hipMemcpyHostToDevice, g_ctx.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dd, docs, n * 4, hipMemcpyHostToDevice, g_ctx.stream);
-    if (e == hipSuccess) e = launch_plant(ix->d_matrix, ix->info.stride, dr, dd, n, g_ctx.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-    (void)hipFree(dr); if (dd) (void)hipFree(dd);
-    if (e != hipSuccess) return fail(PM_EHIP, "plant: %s", hipGetErrorString(e));
-    return PM_OK;
-}
-
-// Synthetic "related batch" content (measurement / test aid, see k_plant_cluster): makes this
-// index the HOME batch of queries q_first, q_first + q_step, ...: about half of its 32-document
-// clusters match each of those queries at a fraction between 0.6 and 1.0.
-extern "C" int pm_index_plant_cluster(pm_index_t* ix, pm_queries_t* q, uint32_t q_first, uint32_t q_step, uint64_t seed) {
-    NEED_DEV();
-    if (!ix || !q || !ix->d_matrix || q_step == 0) return fail(PM_EINVAL, "bad argument (planting works on classic indexes)");
-    if (ix->info.term_size != q->k) return fail(PM_EINVAL, "term_size mismatch");
-    const size_t nq = q->headers.size();
-    if (q_first >= nq) return PM_OK;
-    { int urc = upload_queries(q); if (urc) return urc; }
-    uint64_t* d_h = nullptr;
-    q->epoch++;
-    { int rc = ensure_hashes(q, (int)ix->info.canonicalize, ix->info.num_hashes, &d_h); if (rc) return rc; }
-    const uint32_t n_sel = (uint32_t)((nq - q_first + q_step - 1) / q_step);
-    uint32_t max_terms = 0;
-    for (size_t i = q_first; i < nq; i += q_step) max_terms = std::max(max_terms, q->n_terms[i]);
-    HIPCHK(launch_plant_cluster(ix->d_matrix, ix->info.stride, ix->info.signature_size, ix->info.n_docs, d_h, q->d_qd,
-                                ix->info.num_hashes, q_first, q_step, n_sel, max_terms, seed, g_ctx.stream));
-    HIPCHK(hipStreamSynchronize(g_ctx.stream));
+// The resident matrix of a classic index for code that shares the device with the library (kernels of its own that
+// build or inspect signatures): row r starts at dptr + r * stride, document d is bit d % 8 of byte d / 8.
+extern "C" int pm_index_matrix_device(const pm_index_t* ix, void** dptr, uint64_t* stride) {
+    if (!ix || !dptr || !stride) return fail(PM_EINVAL, "bad argument");
+    if (!ix->d_matrix) return fail(PM_EINVAL, "index has no single resident matrix (header-only, dropped, or a compact index)");
+    *dptr = ix->d_matrix; *stride = ix->info.stride;
     return PM_OK;
 }
 
@@ -585,29 +536,6 @@ extern "C" int pm_index_read_rows(const pm_index_t* ix, uint64_t row0, uint64_t 
     if (n == 0) return PM_OK;
     HIPCHK(hipMemcpy2D(out, ix->info.row_bytes, ix->d_matrix + row0 * ix->info.stride, ix->info.stride,
                        ix->info.row_bytes, n, hipMemcpyDeviceToHost));
-    return PM_OK;
-}
-
-extern "C" int pm_index_probe_gather(const pm_index_t* ix, uint64_t n_groups, uint64_t lookups_per_group,
-                                     double* ms, uint64_t* bytes) {
-    NEED_DEV();
-    if (!ix || !ix->d_matrix || !ms || !bytes || n_groups == 0) return fail(PM_EINVAL, "bad argument");
-    if (ix->slabs != 1) return fail(PM_EINVAL, "probe supports rows up to 1024 bytes");
-    lookups_per_group = (lookups_per_group + 15) / 16 * 16;
-    uint32_t* sink = nullptr;
-    HIPCHK(hipMalloc((void**)&sink, 4));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    hipError_t e = hipEventRecord(e0, g_ctx.stream);
-    if (e == hipSuccess) e = launch_probe_gather(ix->d_matrix, ix->info.stride, ix->info.signature_size, ix->g,
-                                                 n_groups, lookups_per_group, sink, g_ctx.stream);
-    if (e == hipSuccess) e = hipEventRecord(e1, g_ctx.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-    float f = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&f, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
-    if (e != hipSuccess) return fail(PM_EHIP, "probe: %s", hipGetErrorString(e));
-    *ms = f; *bytes = n_groups * lookups_per_group * ix->info.row_bytes;
     return PM_OK;
 }
 

@@ -27,13 +27,14 @@ struct BatchDesc {
     uint32_t prune;             // 1: ScanArgs.prune_n applies to this unit
     uint32_t lanes;             // lanes per row (power of two): read by the mixed-width launch
     uint32_t block_begin;       // first workgroup of this unit in a mixed-width launch
-    uint64_t pad_;
+    uint32_t q_first;           // this unit scans positions q_first ... min(q_end, ScanArgs.nq) - 1 of the launch's query list
+    uint32_t q_end;             // (0, 0xFFFFFFFF: all of them)
 };
 
 struct ScanArgs {
     const BatchDesc* batches;   // batches of this launch (same lanes-per-row class)
     uint32_t        n_batches;
-    uint32_t        tiles;      // workgroups per batch; blockIdx.x = batch*tiles + tile
+    uint32_t        tiles;      // workgroups per batch; blockIdx.x = batch*tiles + tile (a unit with fewer queries leaves its last tiles empty)
     uint32_t        total_blocks;   // mixed-width launch: sum of the per-batch workgroup counts
     const uint64_t* hashes;     // [blk][hash j][8]
     const QDesc*    qd;
@@ -71,18 +72,8 @@ uint32_t scan_queries_per_block(int g, uint32_t wq_groups);   // wq_groups = 0: 
 uint64_t barrett_m(uint64_t S);
 hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst, uint64_t stride,
                            uint64_t n_rows, hipStream_t st);
-hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs,
-                        uint64_t seed, uint32_t batch, hipStream_t st);
-hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
-                               uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st);
-hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, uint32_t n_docs,
-                                const uint64_t* hashes, const QDesc* qd, uint32_t nh,
-                                uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms,
-                                uint64_t seed, hipStream_t st);
 hipError_t launch_publish(const unsigned long long* src, unsigned long long* dst_mapped, int n, hipStream_t st);
 hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* src, uint4* dst, hipStream_t st);
 hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst, hipStream_t st);
-hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
-                        uint64_t n, hipStream_t st);
 
 }  // namespace pm

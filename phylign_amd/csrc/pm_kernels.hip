@@ -11,7 +11,9 @@
 //                     hash functions, carry-save bit-sliced per-document counts
 //                 a7  bit-sliced ">= threshold", ballot/mbcnt compaction of hits
 //                 one launch covers every resident batch of one row-width class
-//   k_restride / k_synth / k_plant   index residency helpers (a4)
+//   k_restride    a4  index residency: file rows -> padded rows in HBM
+// (the synthetic-index generator, the planting kernels and the gather probes are measurement aids and
+// live in csrc/bench/pm_bench_aids.hip -> libphylign_bench.so, not in this library)
 #include "pm_internal.h"
 
 namespace pm {
@@ -301,12 +303,14 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
     const uint32_t gi = ((uint32_t)wave * 64u + (uint32_t)lane) >> gl; // my group inside the workgroup
     const uint32_t ngrp = WQ ? (gpb < a.wq_groups ? gpb : a.wq_groups) : 1u;   // groups that share one query (power of two)
     const uint32_t sub = WQ ? (gi & (ngrp - 1u)) : 0u;
-    const uint32_t li = WQ ? (tile * gpb + gi) / ngrp : tile * gpb + gi;
+    // a unit may be searched with a PART of the launch's queries only (the batch is resident on several ranks that
+    // share its queries: pm_search_async_parts): positions q_first ... q_end - 1 of the class-ordered query list
+    const uint32_t li = (WQ ? (tile * gpb + gi) / ngrp : tile * gpb + gi) + bd.q_first;
     const uint32_t c = (uint32_t)lane & (g - 1u);
     const uint32_t gfirst0 = (uint32_t)lane & ~(g - 1u);               // first lane of my group
     const uint32_t slab = blockIdx.y;
     const uint64_t boff = ((uint64_t)slab * g + c) * 16;   // byte offset of this lane's chunk
-    const bool qv = li < a.nq;
+    const bool qv = li < (bd.q_end < a.nq ? bd.q_end : a.nq);
 
     uint32_t q = 0, nt = 0, thr = 0;
     uint64_t pb = 0;
@@ -780,234 +784,6 @@ hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst,
     return hipGetLastError();
 }
 
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ULL;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
-    return x ^ (x >> 31);
-}
-// Synthetic 661k-shaped matrix: dword j of row r = lo32(u) & hi32(u),
-// u = splitmix64(splitmix64(splitmix64(seed ^ batch*C) + r) + j): P(bit)=1/4.
-__global__ __launch_bounds__(256) void k_synth(
-    uint8_t* __restrict__ dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs, uint64_t kb)
-{
-    const uint64_t chunks_per_row = stride >> 4;
-    const uint64_t total = n_rows * chunks_per_row;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i / chunks_per_row, ch = i - r * chunks_per_row;
-        const uint64_t kr = splitmix64(kb + r);
-        uint32_t w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint64_t j = ch * 4 + k;
-            const uint64_t first_doc = j * 32;
-            uint32_t v = 0;
-            if (first_doc < n_docs) {
-                const uint64_t u = splitmix64(kr + j);
-                v = (uint32_t)u & (uint32_t)(u >> 32);
-                if (first_doc + 32 > n_docs) v &= (1u << (n_docs - first_doc)) - 1u;
-            }
-            w[k] = v;
-        }
-        *reinterpret_cast<uint4*>(dst + r * stride + ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, uint32_t n_docs,
-                        uint64_t seed, uint32_t batch, hipStream_t st) {
-    if (n_rows == 0) return hipSuccess;
-    // kb = splitmix64(seed ^ batch * C) computed on the host side of the launcher
-    uint64_t x = seed ^ ((uint64_t)batch * 0xD1B54A32D192ED03ULL);
-    x += 0x9E3779B97F4A7C15ULL;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
-    const uint64_t kb = x ^ (x >> 31);
-    const uint64_t total = n_rows * (stride >> 4);
-    uint64_t blocks = (total + 255) / 256;
-    if (blocks > 262144) blocks = 262144;
-    hipLaunchKernelGGL(k_synth, dim3((uint32_t)blocks), dim3(256), 0, st, dst, stride, n_rows, n_docs, kb);
-    return hipGetLastError();
-}
-
-// Ceiling probe: the same access pattern as k_scan (random rows, 16 B per lane,
-// G lanes per row, 8 gathers in flight per lane) with the counting replaced by
-// one XOR per load.  Used only to measure what the memory system delivers for
-// this pattern; not part of the matching path.
-template <int G, int U>
-__global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict__ matrix, uint64_t stride,
-                                                       uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink,
-                                                       int mode)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / G;
-    const uint32_t c = lane % G;
-    u32x4 acc = (u32x4)(0u);
-    uint64_t state = splitmix64(group * 0x9E3779B97F4A7C15ULL + 1);
-    const bool active = (uint64_t)c * 16 < stride;
-    // mode 1: ascending stratified rows; mode 2: ascending order statistics of uniform rows
-    // (what a query sees when its k-mers are visited in row order) -- locality experiments
-    float total = 0.f, run = 0.f;
-    if (mode == 2) {
-        uint64_t st2 = state;
-        for (uint64_t i = 0; i <= lookups_per_group; ++i) {
-            st2 = st2 * 6364136223846793005ULL + 1442695040888963407ULL;
-            total += -__logf(((float)(uint32_t)(st2 >> 40) + 1.f) * (1.f / 16777217.f));
-        }
-    }
-    for (uint64_t i = 0; i < lookups_per_group; i += U) {
-        u32x4 v[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            state = state * 6364136223846793005ULL + 1442695040888963407ULL;
-            uint64_t r = __umul64hi(state, n_rows);
-            if (mode == 1) r = (uint64_t)(((double)(i + k) + (double)(state >> 11) * (1.0 / 9007199254740992.0)) / (double)lookups_per_group * (double)n_rows);
-            if (mode == 2) {
-                run += -__logf(((float)(uint32_t)(state >> 40) + 1.f) * (1.f / 16777217.f));
-                r = (uint64_t)((double)(run / total) * (double)(n_rows - 1));
-            }
-            if (r >= n_rows) r = n_rows - 1;
-            v[k] = (u32x4)(0u);
-            if (active) v[k] = *reinterpret_cast<const u32x4*>(matrix + r * stride + (uint64_t)c * 16);
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) acc ^= v[k];
-    }
-    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;   // keeps the loads alive
-}
-// Cache-policy flavours of the same gather (PM_PROBE_FLAVOR = 1 ... 5): does a gather that needs 16-64 bytes of a
-// 128-byte line cost less on the fabric when it bypasses / streams through the caches?  F: 1 = nt, 2 = sc1,
-// 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc0.  Inline asm: the waits are explicit (the compiler does not track these loads).
-#define PM_PROBE_LOAD(F, dst, ptr)                                                                                    \
-    do {                                                                                                              \
-        if constexpr (F == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory");          \
-        else if constexpr (F == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory");    \
-        else if constexpr (F == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(ptr) : "memory"); \
-        else if constexpr (F == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(dst) : "v"(ptr) : "memory"); \
-        else asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(dst) : "v"(ptr) : "memory");                    \
-    } while (0)
-template <int G, int F>
-__global__ __launch_bounds__(256) void k_probe_flavor(const uint8_t* __restrict__ matrix, uint64_t stride,
-                                                       uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / G;
-    const uint32_t c = lane % G;
-    u32x4 acc = (u32x4)(0u);
-    uint64_t state = splitmix64(group * 0x9E3779B97F4A7C15ULL + 1);
-    const uint64_t coff = ((uint64_t)c * 16 < stride) ? (uint64_t)c * 16 : 0;     // every lane loads (asm loads are unconditional)
-    for (uint64_t i = 0; i < lookups_per_group; i += 8) {
-        u32x4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            state = state * 6364136223846793005ULL + 1442695040888963407ULL;
-            uint64_t r = __umul64hi(state, n_rows);
-            const uint8_t* p = matrix + r * stride + coff;
-            PM_PROBE_LOAD(F, v[k], p);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc ^= v[k];
-    }
-    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
-}
-template <int G>
-static void probe_launch_flavor(int flavor, dim3 grid, hipStream_t st, const uint8_t* matrix, uint64_t stride,
-                                uint64_t n_rows, uint64_t per, uint32_t* sink) {
-    switch (flavor) {
-        case 1: hipLaunchKernelGGL((k_probe_flavor<G, 1>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
-        case 2: hipLaunchKernelGGL((k_probe_flavor<G, 2>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
-        case 3: hipLaunchKernelGGL((k_probe_flavor<G, 3>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
-        case 4: hipLaunchKernelGGL((k_probe_flavor<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
-        default: hipLaunchKernelGGL((k_probe_flavor<G, 5>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink); break;
-    }
-}
-template <int G>
-static void probe_launch_u(int unroll, dim3 grid, hipStream_t st, const uint8_t* matrix, uint64_t stride,
-                           uint64_t n_rows, uint64_t per, uint32_t* sink) {
-    int mode = 0;
-    if (const char* m = getenv("PM_PROBE_MODE")) mode = atoi(m);
-    if (const char* f = getenv("PM_PROBE_FLAVOR")) if (atoi(f) > 0) { probe_launch_flavor<G>(atoi(f), grid, st, matrix, stride, n_rows, per, sink); return; }
-    if (unroll == 4)       hipLaunchKernelGGL((k_probe_gather<G, 4>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
-    else if (unroll == 16) hipLaunchKernelGGL((k_probe_gather<G, 16>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
-    else                   hipLaunchKernelGGL((k_probe_gather<G, 8>), grid, dim3(256), 0, st, matrix, stride, n_rows, per, sink, mode);
-}
-hipError_t launch_probe_gather(const uint8_t* matrix, uint64_t stride, uint64_t n_rows, int g,
-                               uint64_t groups, uint64_t lookups_per_group, uint32_t* sink, hipStream_t st) {
-    const uint64_t threads = groups * (uint64_t)g;
-    dim3 grid((uint32_t)((threads + 255) / 256));
-    int unroll = 8;
-    if (const char* u = getenv("PM_PROBE_UNROLL")) unroll = atoi(u);
-    switch (g) {
-        case 1:  probe_launch_u<1>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 2:  probe_launch_u<2>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 4:  probe_launch_u<4>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 8:  probe_launch_u<8>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 16: probe_launch_u<16>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 32: probe_launch_u<32>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        case 64: probe_launch_u<64>(unroll, grid, st, matrix, stride, n_rows, lookups_per_group, sink); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-// Clustered true positives for the "phylogenetically related batch" workload: for every
-// selected query (its HOME batch is this index) the documents are taken in clusters of 32
-// (one dword of the row); cluster c gets a match fraction phi(query, c) from
-// {none x8, 0.60, 0.70, 0.75, 0.85, 0.93, 0.97, 1.0, 1.0} (half of the clusters unrelated) and
-// every k-mer row of the query gets, in that dword, an OR-mask of independent bits of density phi.
-// So many documents end up near the 0.7 threshold, above and below it.  One thread per
-// (selected query, k-mer, dword).  Set-up only, never timed.
-__global__ __launch_bounds__(256) void k_plant_cluster(
-    uint8_t* matrix, uint64_t stride, uint64_t S, uint64_t bm, uint32_t n_docs,
-    const uint64_t* __restrict__ hashes, const QDesc* __restrict__ qd, uint32_t nh,
-    uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms, uint64_t seed)
-{
-    const uint32_t n_dw = (n_docs + 31u) >> 5;
-    const uint64_t total = (uint64_t)n_sel * max_terms * n_dw;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t dw = (uint32_t)(i % n_dw);
-        const uint64_t r1 = i / n_dw;
-        const uint32_t t = (uint32_t)(r1 % max_terms);
-        const uint32_t qi = q_first + (uint32_t)(r1 / max_terms) * q_step;
-        const QDesc d = qd[qi];
-        if (t >= d.n_terms) continue;
-        const uint64_t kc = splitmix64(seed ^ ((uint64_t)qi * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)dw << 40));
-        const uint32_t sel = (uint32_t)(kc & 15u);
-        if (sel < 8u) continue;                                    // unrelated cluster
-        const uint32_t lut[8] = {154u, 179u, 192u, 218u, 238u, 248u, 256u, 256u};   // phi * 256
-        const uint32_t cut = lut[sel - 8u];
-        uint32_t m = 0;
-        uint64_t x = splitmix64(kc + 0x51ED270B1ULL * (t + 1u));
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            x = splitmix64(x + (uint64_t)w);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) m |= (((uint32_t)(x >> (8 * b)) & 255u) < cut ? 1u : 0u) << (8 * w + b);
-        }
-        const uint32_t first = dw * 32u;
-        if (first + 32u > n_docs) m &= (1u << (n_docs - first)) - 1u;
-        if (m == 0u) continue;
-        for (uint32_t j = 0; j < nh; ++j) {
-            const uint64_t h = hashes[((uint64_t)d.pad_blk + (t >> 3)) * nh * 8 + (uint64_t)j * 8 + (t & 7u)];
-            uint32_t* w = reinterpret_cast<uint32_t*>(matrix + mod_sig(h, S, bm) * stride + (uint64_t)dw * 4);
-            atomicOr(w, m);
-        }
-    }
-}
-hipError_t launch_plant_cluster(uint8_t* matrix, uint64_t stride, uint64_t S, uint32_t n_docs,
-                                const uint64_t* hashes, const QDesc* qd, uint32_t nh,
-                                uint32_t q_first, uint32_t q_step, uint32_t n_sel, uint32_t max_terms,
-                                uint64_t seed, hipStream_t st) {
-    const uint64_t total = (uint64_t)n_sel * max_terms * ((n_docs + 31u) >> 5);
-    if (total == 0) return hipSuccess;
-    uint64_t blocks = (total + 255) / 256;
-    if (blocks > 262144) blocks = 262144;
-    hipLaunchKernelGGL(k_plant_cluster, dim3((uint32_t)blocks), dim3(256), 0, st, matrix, stride, S, barrett_m(S),
-                       n_docs, hashes, qd, nh, q_first, q_step, n_sel, max_terms, seed);
-    return hipGetLastError();
-}
-
 // copies n 64-bit words to device-mapped host memory (record counters of a search)
 __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* dst, int n) {
     if ((int)threadIdx.x < n) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1091,20 +867,6 @@ __global__ __launch_bounds__(256) void k_merge_runs(const uint4* __restrict__ gr
 hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst, hipStream_t st) {
     if (n_groups == 0) return hipSuccess;
     hipLaunchKernelGGL(k_merge_runs, dim3(n_groups < 65536u ? n_groups : 65536u), dim3(256), 0, st, groups, n_groups, runs, src, dst);
-    return hipGetLastError();
-}
-
-__global__ void k_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t d = docs[i];
-    uint32_t* w = reinterpret_cast<uint32_t*>(matrix + rows[i] * stride + (uint64_t)(d >> 5) * 4);
-    atomicOr(w, 1u << (d & 31));
-}
-hipError_t launch_plant(uint8_t* matrix, uint64_t stride, const uint64_t* rows, const uint32_t* docs,
-                        uint64_t n, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_plant, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, matrix, stride, rows, docs, n);
     return hipGetLastError();
 }
 

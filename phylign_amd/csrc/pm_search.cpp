@@ -102,8 +102,14 @@ static void give_pinned(PinBuf b) {
 }
 
 // One scan unit per classic index or per sub-index of a compact index.
-struct Unit { const pm_index* ix; uint32_t slot, doc_base; bool prune; };
-struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; };
+struct Unit { const pm_index* ix; uint32_t slot, doc_base; bool prune; pm_qpart_t part; };
+struct Group { int g, canon; uint32_t nh, slabs; std::vector<size_t> members; bool has_parts; };
+// positions [first, end) of a class of n queries that part `p` of an index covers (den == 0: all of them)
+static inline void part_range(const pm_qpart_t& p, uint32_t n, uint32_t* first, uint32_t* end) {
+    if (p.den == 0) { *first = 0; *end = n; return; }
+    *first = (uint32_t)((uint64_t)p.lo * n / p.den);
+    *end = (uint32_t)((uint64_t)p.hi * n / p.den);
+}
 
 struct pm_result {
     // what was asked (kept for the one re-run after a hit-buffer overflow)
@@ -111,6 +117,7 @@ struct pm_result {
     pm_queries* q = nullptr;
     double threshold = 0;
     uint32_t nb_best = 0, slot_base = 0;
+    std::vector<pm_qpart_t> parts;                // empty, or the part of the queries every index is searched with
     // device output
     uint4* d_hits = nullptr;
     uint64_t cap = 0;
@@ -153,25 +160,30 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     std::vector<Unit> units;
     for (size_t s = 0; s < n_idx; ++s) {
         const pm_index* ix = r->idx[s];
+        const pm_qpart_t part = r->parts.empty() ? pm_qpart_t{0, 0, 0} : r->parts[s];
         if (ix->parts.empty()) {
             if (!ix->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
             // names without '_' make the reference's post-filter raise on a line it would otherwise
             // drop (scripts/postprocess_cobs.py:10-18): such an index is cut on the host, where
             // every document that passed -t is seen, so both ways to prune fail alike
-            units.push_back({ix, r->slot_base + (uint32_t)s, 0u, ix->names_have_sep});
+            units.push_back({ix, r->slot_base + (uint32_t)s, 0u, ix->names_have_sep, part});
         } else {
             // the n best documents of a compact index span its sub-indexes: cut when formatting
             for (size_t p = 0; p < ix->parts.size(); ++p) {
-                const pm_index* part = ix->parts[p];
-                if (part->info.n_docs == 0) continue;
-                if (!part->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
-                units.push_back({part, r->slot_base + (uint32_t)s, (uint32_t)(p * ix->page_size * 8), false});
+                const pm_index* sub = ix->parts[p];
+                if (sub->info.n_docs == 0) continue;
+                if (!sub->d_matrix) return fail(PM_EINVAL, "index %zu has no matrix", s);
+                units.push_back({sub, r->slot_base + (uint32_t)s, (uint32_t)(p * ix->page_size * 8), false, part});
             }
         }
     }
     const size_t nq = q->headers.size();
     hipStream_t st = g_ctx.stream;
     { int urc = upload_queries(q); if (urc) return urc; }
+    if (q->term_prefix.size() != nq + 1) {            // k-mers ahead of every position of the class-ordered query list
+        q->term_prefix.assign(nq + 1, 0);
+        for (size_t i = 0; i < nq; ++i) q->term_prefix[i + 1] = q->term_prefix[i] + q->n_terms[q->qmap[i]];
+    }
 
     // ---- launch plan: one scan launch per (lanes-per-row class, canonicalize,
     // num_hashes) x counter-width class covers every unit of that class;
@@ -187,8 +199,9 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         if (ix->slabs == 1)
             for (auto& g : groups)
                 if (g.slabs == 1 && g.g == key && g.canon == (int)ix->info.canonicalize && g.nh == ix->info.num_hashes) gp = &g;
-        if (!gp) { groups.push_back({key, (int)ix->info.canonicalize, ix->info.num_hashes, ix->slabs, {}}); gp = &groups.back(); }
+        if (!gp) { groups.push_back({key, (int)ix->info.canonicalize, ix->info.num_hashes, ix->slabs, {}, false}); gp = &groups.back(); }
         gp->members.push_back(u);
+        if (units[u].part.den) gp->has_parts = true;
     }
     for (auto& g : groups)      // a mixed group with one width is an ordinary group
         if (g.g == 0) {
@@ -229,7 +242,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
                 d.matrix = ix->d_matrix; d.stride = ix->info.stride; d.sig_size = ix->info.signature_size;
                 d.barrett_m = barrett_m(ix->info.signature_size); d.n_docs = ix->info.n_docs;
                 d.slot = units[u].slot; d.doc_base = units[u].doc_base; d.prune = units[u].prune ? 1u : 0u;
-                d.lanes = (uint32_t)ix->g; d.block_begin = 0; d.pad_ = 0;
+                d.lanes = (uint32_t)ix->g; d.block_begin = 0; d.q_first = 0; d.q_end = 0xFFFFFFFFu;
             }
     }
     // wide-query form per (group, query class): when one lane group per query would leave the chip
@@ -261,25 +274,32 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             while (grp < 256 && grp < want) grp <<= 1;
             use_wq[gi * kNumClasses + (size_t)c] = grp;
         }
+    // per query class: the workgroup ranges of mixed launches, and -- groups with query parts -- every unit's query range
+    // (mixed launch: total workgroups; uniform launch with parts: tiles of the unit with the most queries)
     std::vector<uint32_t> mixed_blocks(groups.size() * kNumClasses, 0u);
     {
         size_t desc_off = 0;
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             Group& g = groups[gi];
-            if (g.g == 0)
+            if (g.g == 0 || g.has_parts)
                 for (int c = 0; c < kNumClasses; ++c) {
                     const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
                     if (e == b) continue;
-                    uint64_t blk = 0;
+                    uint64_t blk = 0, most = 0;
                     BatchDesc* stage = ws->h_desc + (size_t)(1 + c) * dcap + desc_off;
                     for (size_t k = 0; k < g.members.size(); ++k) {
                         stage[k] = ws->h_desc[desc_off + k];
                         const uint32_t qpb = scan_queries_per_block((int)stage[k].lanes, use_wq[gi * kNumClasses + (size_t)c]);
+                        uint32_t first, end;
+                        part_range(units[g.members[k]].part, e - b, &first, &end);
+                        stage[k].q_first = first; stage[k].q_end = end;
                         stage[k].block_begin = (uint32_t)blk;
-                        blk += (e - b + qpb - 1) / qpb;
+                        const uint64_t t = (end - first + qpb - 1) / qpb;
+                        blk += t;
+                        most = std::max(most, t);
                     }
                     if (blk > 0x7FFFFFFFull) return fail(PM_ERANGE, "launch grid too large");
-                    mixed_blocks[gi * kNumClasses + (size_t)c] = (uint32_t)blk;
+                    mixed_blocks[gi * kNumClasses + (size_t)c] = (uint32_t)(g.g == 0 ? blk : most);
                 }
             desc_off += g.members.size();
         }
@@ -324,8 +344,6 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     size_t desc_off = 0;
     for (auto& g : groups) {
         { int rc = ensure_hashes(q, g.canon, g.nh, &d_h); if (rc) return rc; }
-        uint64_t rowsum = 0;
-        for (size_t u : g.members) rowsum += units[u].ix->info.row_bytes;
         for (int c = 0; c < kNumClasses; ++c) {
             const uint32_t b = q->class_begin[c], e = q->class_begin[c + 1];
             if (e == b) continue;
@@ -335,13 +353,19 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             a.wq_groups = use_wq[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
             a.wide_query = a.wq_groups ? 1u : 0u;
             a.nsplit = 1; a.pad2_ = 0; a.split_slabs = nullptr; a.split_cnt = nullptr;
-            if (g.g > 0) {
+            if (g.g > 0 && g.has_parts) {
+                // the slice of this query class holds every unit's query range; a unit with fewer queries leaves tiles empty
+                a.batches = ws->d_desc + (size_t)(1 + c) * dcap + desc_off;
+                a.tiles = mixed_blocks[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
+                if (a.tiles == 0) continue;
+            } else if (g.g > 0) {
                 const uint32_t qpb = scan_queries_per_block(g.g, a.wq_groups);
                 a.tiles = (e - b + qpb - 1) / qpb;
             } else {
                 // mixed widths: the slice of this query class holds the per-batch workgroup ranges
                 a.batches = ws->d_desc + (size_t)(1 + c) * dcap + desc_off;
                 a.total_blocks = mixed_blocks[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
+                if (a.total_blocks == 0) continue;
             }
             a.hashes = d_h; a.qd = q->d_qd; a.thr = q->d_thr; a.qmap = q->d_qmap + b; a.nq = e - b;
             a.prune_n = r->nb_best;
@@ -397,13 +421,19 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
                 HIPCHK(hipMemcpyAsync(r->h_fetch + r->launches.size() * kFetchShards, g_ctx.d_fetch,
                                       kFetchShards * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             r->lev.push_back({es, ee});
-            uint64_t terms = 0;
-            for (uint32_t i = b; i < e; ++i) terms += q->n_terms[q->qmap[i]];
+            // k-mers x row bytes of what the launch covers (a unit with a query part counts its queries only)
+            const uint64_t* tp = q->term_prefix.data();
+            uint64_t alg_l = 0;
+            for (size_t u : g.members) {
+                uint32_t first, end;
+                part_range(units[u].part, e - b, &first, &end);
+                alg_l += (tp[b + end] - tp[b + first]) * g.nh * units[u].ix->info.row_bytes;
+            }
             pm_launch_t L{};
             L.lanes_per_row = (uint32_t)g.g; L.planes = (uint32_t)kPlaneClass[c]; L.num_hashes = g.nh;
             L.wide_query = a.wide_query;
             L.n_batches = a.n_batches; L.n_queries = e - b;
-            L.algorithmic_bytes = terms * g.nh * rowsum;
+            L.algorithmic_bytes = alg_l;
             r->launches.push_back(L);
             alg += L.algorithmic_bytes;
         }
@@ -475,8 +505,18 @@ static int result_wait_impl(pm_result_t* r) {
 
 extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                                double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
+    return pm_search_async_parts(idx, n_idx, q, threshold, nb_best_hits, slot_base, nullptr, out);
+}
+
+extern "C" int pm_search_async_parts(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
+                                     double threshold, uint32_t nb_best_hits, uint32_t slot_base,
+                                     const pm_qpart_t* parts, pm_result_t** out) {
     NEED_DEV();
     if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
+    if (parts)
+        for (size_t s = 0; s < n_idx; ++s)
+            if (parts[s].den && (parts[s].lo > parts[s].hi || parts[s].hi > parts[s].den))
+                return fail(PM_EINVAL, "index %zu: query part [%u, %u) of %u", s, parts[s].lo, parts[s].hi, parts[s].den);
     if (!(threshold >= 0.0)) return fail(PM_EINVAL, "threshold must be >= 0");
     for (size_t s = 0; s < n_idx; ++s) {
         if (!idx[s]) return fail(PM_EINVAL, "index %zu is null", s);
@@ -486,6 +526,7 @@ extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_
     pm_result* r = new pm_result();
     r->idx.assign(idx, idx + n_idx);
     r->q = q; r->threshold = threshold; r->nb_best = nb_best_hits; r->slot_base = slot_base;
+    if (parts) r->parts.assign(parts, parts + n_idx);
     uint64_t hint;
     { std::lock_guard<std::mutex> lk(g_pool_mu); hint = g_ctx.hit_hint; }
     // first guess of the record count: 48 per query (a read that matches its species' batch brings ~100 records after the

@@ -41,40 +41,69 @@ def gather_hits(local, dst=0, group=None):
 
 
 class PackedGather:
-    """One-collective form of gather_hits for a step loop: every rank owns a fixed
-    [cap + 1, 4] int32 buffer whose row 0 carries its record count; one
+    """One-collective form of gather_hits for a step loop: every rank owns fixed
+    [cap + 1, 4] int32 buffers whose row 0 carries the record count; one
     `dist.gather` moves all of them to rank 0 (with RCCL: 7 peer-to-root
     transfers over 7 distinct xGMI links).  A rank with more than `cap` records
     announces its count and ships the records in a second, point-to-point
-    message, so the result never depends on `cap`."""
+    message, so the result never depends on `cap`.
 
-    def __init__(self, cap, device, group=None):
+    The send buffers alternate (`depth` of them): with RCCL the collective is
+    only QUEUED when dist.gather returns, and the next step fills the OTHER
+    buffer, so a non-root rank never waits for its send -- an event recorded
+    behind the collective is waited for only when the buffer comes round again,
+    one whole step later.  The gather of step i thus overlaps the scan of step
+    i + 1 on every rank."""
+
+    def __init__(self, cap, device, group=None, depth=2):
         self.cap, self.group, self.device = int(cap), group, device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.pack = torch.zeros((self.cap + 1, 4), dtype=torch.int32, device=device)
-        self.recv = [torch.zeros_like(self.pack) for _ in range(self.world)] if self.rank == 0 and self.world > 1 else None
+        self.packs = [torch.zeros((self.cap + 1, 4), dtype=torch.int32, device=device) for _ in range(max(1, depth))]
+        self.sent = [None] * len(self.packs)         # event behind the last collective that read packs[i]
+        self.turn = 0
+        self.recv = [torch.zeros_like(self.packs[0]) for _ in range(self.world)] if self.rank == 0 and self.world > 1 else None
+        self.waited_s = 0.0                          # host time spent waiting for a buffer to come free (should stay ~0)
+
+    @property
+    def pack(self):
+        return self.packs[self.turn]
 
     def records_view(self):
-        """rows 1.. of the local buffer: the place to copy up to `cap` records into"""
-        return self.pack[1:]
+        """rows 1.. of the current send buffer: the place to copy up to `cap` records into (waits until the collective
+        that last read this buffer has finished)"""
+        ev = self.sent[self.turn]
+        if ev is not None:
+            if not ev.query():
+                import time
+                t0 = time.perf_counter()
+                ev.synchronize()
+                self.waited_s += time.perf_counter() - t0
+            self.sent[self.turn] = None
+        return self.packs[self.turn][1:]
 
     def gather(self, count, overflow=None, dst=0):
         """count: number of valid rows in records_view(), or the true count when
         it exceeds cap and `overflow` (int32 [count, 4]) holds all records."""
         assert dst == 0
+        pack = self.packs[self.turn]
         if self.world == 1:
-            return overflow if count > self.cap else self.pack[1:1 + count]
-        self.pack[0, 0] = int(count)
-        dist.gather(self.pack, self.recv, dst=0, group=self.group)
+            return overflow if count > self.cap else pack[1:1 + count]
+        self.records_view()                           # (no-op when the caller filled the buffer through records_view())
+        pack[0, 0] = int(count)
+        dist.gather(pack, self.recv, dst=0, group=self.group)
         if self.rank != 0:
             if count > self.cap:
                 dist.send(overflow.contiguous(), 0, group=self.group)
-            if self.pack.is_cuda:
-                # with RCCL the collective is only QUEUED when dist.gather returns: the next step refills
-                # `pack` from another stream, so the send must have left the buffer first
-                torch.cuda.current_stream(self.pack.device).synchronize()
+                if pack.is_cuda:                      # `overflow` is the caller's: it must have left before we return
+                    torch.cuda.current_stream(pack.device).synchronize()
+            elif pack.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(pack.device))      # the stream waits for the collective (work.wait())
+                self.sent[self.turn] = ev
+            self.turn = (self.turn + 1) % len(self.packs)
             return None
+        self.turn = (self.turn + 1) % len(self.packs)
         counts = torch.stack([r[0, 0] for r in self.recv]).cpu().tolist()
         parts = []
         for r, c in enumerate(counts):

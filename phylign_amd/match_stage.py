@@ -6,7 +6,8 @@ decompress_and_run_cobs, then Snakefile:490-520 rule translate_matches).
     python -m phylign_amd.match_stage --batches data/batches_full.txt --cobs-dir cobs \
         --sizes data/decompressed_indexes_sizes.txt --queries intermediate/01_queries_merged/Q.fa \
         --out-dir intermediate/03_match [--filter-out intermediate/04_filter/Q.fa]
-    python -m torch.distributed.run --nproc-per-node 8 ... -m phylign_amd.match_stage ...   # one rank per GPU
+    python -m phylign_amd.match_stage --gpus 8 ...                                          # starts its own 8 ranks, one per GPU
+    python -m torch.distributed.run --nproc-per-node 8 ... -m phylign_amd.match_stage ...   # or under a launcher
 
 Per rank (static batch -> rank map on scan cost, workload.assign_named):
 
@@ -428,7 +429,15 @@ def main(argv=None):
     ap.add_argument("--synthetic", default=None, metavar="WORKLOAD[:WORLD:RANK]",
                     help="measurement aid: 661k-shaped synthetic signatures generated in HBM instead of --cobs-dir files "
                          "(workload.select name; WORLD:RANK = hold only that shard of a WORLD-way split)")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="ranks (one per GPU) to start when the command is not run under a launcher: a plain "
+                         "`python -m phylign_amd.match_stage --gpus 8 ...` starts 8 fresh ranks of itself (0 = what the launcher "
+                         "says, or one)")
     args = ap.parse_args(argv)
+    from . import launch
+    if launch.wants_self_launch(args.gpus):
+        # this process has not touched the GPU: start the ranks as children, relay their status
+        sys.exit(launch.self_launch_module("phylign_amd.match_stage", sys.argv[1:] if argv is None else argv, args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

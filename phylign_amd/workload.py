@@ -115,6 +115,70 @@ def assign_batches(shapes, n_ranks, capacity_bytes=None):
     return [sorted(x) for x in out]
 
 
+PART_DEN = 1024          # query shares are expressed in 1/1024 of the query set (pm_qpart_t.den)
+# the part of scan_cost a batch costs whatever share of the queries it is searched with
+_BATCH_FIXED = int(os.environ.get("PHYLIGN_BATCH_FIXED", "25"))
+
+
+def assign_parts(shapes, n_ranks, capacity_bytes=None, max_replica_bytes=4 << 30, tolerance=0.004):
+    """assign_batches, then the residual imbalance (whole batches: the heaviest of 8 ranks is left ~4 % above the mean on the
+    64 batches of config 3) is levelled by making a few SMALL batches resident on two ranks that share their queries:
+    the heaviest rank hands the upper end of one batch's query range to the lightest one (pm_search_async_parts), sized so
+    that one of them reaches the mean under cost(share) = _BATCH_FIXED + share * (scan_cost - _BATCH_FIXED).  Only batches of at most
+    max_replica_bytes are replicated (the narrow one-line batches; a replica costs its HBM a second time).
+    Returns per rank a list of (position in shapes, lo, hi) sorted by position: the rank searches the batch with the
+    queries of share [lo, hi) / PART_DEN; (pos, 0, PART_DEN) is a whole batch."""
+    whole = assign_batches(shapes, n_ranks, capacity_bytes)
+    held = [{pos: [0, PART_DEN] for pos in part} for part in whole]
+    if n_ranks < 2:
+        return [[(pos, 0, PART_DEN) for pos in part] for part in whole]
+    var = [max(1, scan_cost(s) - _BATCH_FIXED) for s in shapes]
+
+    def load_of(r):
+        return sum(_BATCH_FIXED + var[p] * (hi - lo) / PART_DEN for p, (lo, hi) in held[r].items())
+
+    def used_of(r):
+        return sum(shapes[p].index_bytes for p in held[r])
+    for _ in range(4 * n_ranks):
+        load = [load_of(r) for r in range(n_ranks)]
+        a = max(range(n_ranks), key=lambda r: (load[r], -r))
+        b = min(range(n_ranks), key=lambda r: (load[r], r))
+        # the mean every rank should reach once b paid the fixed cost of one more resident batch; the transfer brings the
+        # heaviest rank down to it or the lightest one up to it, whichever is less (n - 1 transfers level n ranks)
+        target = (sum(load) + _BATCH_FIXED) / n_ranks
+        amount = min(load[a] - target, target - load[b] - _BATCH_FIXED)
+        if amount <= tolerance * target:
+            # nobody is far enough below the mean to take a share AND its fixed cost up to the mean: level the pair instead
+            amount = (load[a] - load[b] - _BATCH_FIXED) / 2.0
+            if amount <= tolerance * target:
+                break                                                                # not worth a second resident copy
+        best = None
+        for p, (lo, hi) in held[a].items():
+            if p in held[b] or hi - lo != PART_DEN or shapes[p].index_bytes > max_replica_bytes:
+                continue                                                             # a batch is shared by two ranks at most
+            if capacity_bytes is not None and used_of(b) + shapes[p].index_bytes > capacity_bytes:
+                continue
+            x = int(round(amount / var[p] * PART_DEN))
+            if not 0 < x < PART_DEN:
+                continue
+            key = (shapes[p].index_bytes, p)                                         # the cheapest replica that can carry it
+            if best is None or key < best[0]:
+                best = (key, p, x)
+        if best is None:
+            break
+        _, p, x = best
+        lo, hi = held[a][p]
+        held[a][p] = [lo, hi - x]
+        held[b][p] = [hi - x, hi]
+    return [sorted((p, lo, hi) for p, (lo, hi) in h.items()) for h in held]
+
+
+def parts_cost(shapes, parts):
+    """modelled scan cost of every rank of an assign_parts() result"""
+    return [sum(_BATCH_FIXED + max(1, scan_cost(shapes[p]) - _BATCH_FIXED) * (hi - lo) / PART_DEN for p, lo, hi in part)
+            for part in parts]
+
+
 def assign_named(batches, sizes, n_ranks, capacity_bytes=None):
     """assign_batches for a real batch list (match_stage): `batches` are names, `sizes` maps a name to
     its decompressed index bytes (data/decompressed_indexes_sizes.txt).  A batch of the 661k collection

@@ -193,3 +193,95 @@ def test_effective_cpus_is_positive_and_bounded():
     from phylign_amd.sysinfo import effective_cpus
     n = effective_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_assign_parts_shares_partition_every_batch_and_level_the_ranks():
+    """workload.assign_parts: every batch is whole on one rank or shared by exactly two whose query shares tile
+    [0, PART_DEN); replicas are small batches within the capacity; priced with the per-batch scan times MEASURED on one
+    MI355X (a share costs that share of the batch's time) the slowest of 8 ranks is within 2 % of the mean"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cost = {}
+    with open(os.path.join(root, "profiles", "r03", "per_batch_cost.tsv")) as f:
+        head = f.readline().rstrip("\n").split("\t")
+        for line in f:
+            row = dict(zip(head, line.rstrip("\n").split("\t")))
+            cost[row["batch"]] = (float(row["ms_fetch_all"]), float(row["ms_bound"]))
+    shapes = W.select("config3")
+    for n in (1, 2, 3, 4, 5, 8):
+        parts = W.assign_parts(shapes, n)
+        assert parts == W.assign_parts(shapes, n) and len(parts) == n
+        cover = {}
+        for r, part in enumerate(parts):
+            assert part == sorted(part) and len({p for p, _, _ in part}) == len(part)
+            for p, lo, hi in part:
+                assert 0 <= lo < hi <= W.PART_DEN
+                cover.setdefault(p, []).append((lo, hi, r))
+        assert sorted(cover) == list(range(64))
+        for p, iv in cover.items():
+            iv.sort()
+            assert len(iv) <= 2 and iv[0][0] == 0 and iv[-1][1] == W.PART_DEN
+            assert all(a[1] == b[0] for a, b in zip(iv, iv[1:]))
+            if len(iv) == 2:
+                assert shapes[p].index_bytes <= 4 << 30 and iv[0][2] != iv[1][2]
+        modelled = W.parts_cost(shapes, parts)
+        assert max(modelled) / (sum(modelled) / n) <= 1.012, (n, modelled)
+        if n in (2, 4, 8):
+            for mode in (0, 1):
+                loads = [sum(cost[shapes[p].batch][mode] * (hi - lo) / W.PART_DEN for p, lo, hi in part) for part in parts]
+                assert max(loads) / (sum(loads) / n) <= 1.02, (n, mode, loads)
+    # capacity: a replica never pushes a rank over it
+    full = W.select("full")
+    cap = int(288e9 * 0.85)
+    parts = W.assign_parts(full, 8, capacity_bytes=cap)
+    assert all(sum(full[p].index_bytes for p, _, _ in part) <= cap for part in parts)
+    assert sorted({p for part in parts for p, _, _ in part}) == list(range(305))
+
+
+def test_self_launch_starts_fresh_ranks_and_relays_status(tmp_path):
+    """phylign_amd.launch: `--gpus N` without a launcher = N children with the environment torch.distributed.run would
+    give them; the job's status is the first failing rank's, and the other ranks are ended"""
+    import subprocess
+    import sys
+    import time
+    from phylign_amd import launch
+    assert launch.wants_self_launch(8, {}) and not launch.wants_self_launch(1, {})
+    assert not launch.wants_self_launch(8, {"WORLD_SIZE": "8", "RANK": "0"})
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "open(os.path.join(sys.argv[1], f'seen{r}'), 'w').write(str(w))\n"
+        "if len(sys.argv) > 2 and r == int(sys.argv[2]):\n"
+        "    sys.exit(7)\n"
+        "if len(sys.argv) > 2:\n"
+        "    time.sleep(60)\n"
+        "if r == 0:\n"
+        "    print('{\"line\": 1}')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom phylign_amd import launch\n"
+            "sys.exit(launch.self_launch_script(%r, sys.argv[1:], 5))\n" % (root, str(script)))
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.decode().strip() == '{"line": 1}', r.stderr.decode()
+    assert sorted(f.name for f in tmp_path.glob("seen*")) == [f"seen{i}" for i in range(5)]
+    assert (tmp_path / "seen3").read_text() == "5"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path), "2"], capture_output=True, timeout=60)
+    assert r.returncode == 7 and time.time() - t0 < 30 and b"rank 2 exited with status 7" in r.stderr
+
+
+def test_bench_and_stage_self_launch_before_touching_the_gpu():
+    """`python bench.py --gpus 2` / `python -m phylign_amd.match_stage --gpus 2` in a box without a GPU: the parent
+    starts the ranks (no torch import, no HIP call in the parent), every rank fails loudly, the status is relayed"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the CPU form of this check")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"[launch] rank" in r.stderr and b"needs an MI355X" in r.stderr and r.stdout == b""
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--gpus", "2", "--synthetic", "small", "--queries", os.devnull,
+                        "--out-dir", os.devnull], capture_output=True, timeout=300, cwd="/", env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode != 0 and b"[launch] rank" in r.stderr

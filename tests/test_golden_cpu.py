@@ -214,6 +214,32 @@ def test_c_abi_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_product_library_exports_only_the_drop_in_abi():
+    """nm -D: libphylign_match.so exports exactly the entry points of include/phylign_match.h -- no measurement aid
+    (synthetic indexes, planting, probes live in libphylign_bench.so behind include/phylign_match_bench.h), no C++
+    internals, no kernel stubs; and the product library reads no PM_PROBE_* variable"""
+    import subprocess
+    from phylign_amd import _lib, bench_aids
+    hdr = open(os.path.join(ROOT, "include", "phylign_match.h")).read()
+    declared = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, exported ^ declared
+    assert not any(w in name for name in exported for w in ("synth", "plant", "probe", "bench"))
+    assert b"PM_PROBE" not in open(_lib.LIB_PATH, "rb").read()
+    bhdr = open(os.path.join(ROOT, "include", "phylign_match_bench.h")).read()
+    bdecl = set(re.findall(r"\b(pm_bench_[a-z0-9_]+)\s*\(", bhdr))
+    out = subprocess.run(["nm", "-D", "--defined-only", bench_aids.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bexp = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert bexp == bdecl == {s_[0] for s_ in bench_aids.SYMBOLS}, bexp ^ bdecl
+    L = bench_aids.load()
+    for name in bdecl:
+        assert getattr(L, name) is not None
+    # the drop-in modules never import the aids
+    for mod in ("cobs_query.py", "postprocess.py", "filter_queries.py", "server.py", "fix_query.py", "dist.py", "launch.py"):
+        assert "bench_aids" not in open(os.path.join(ROOT, "phylign_amd", mod)).read(), mod
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -467,3 +467,23 @@ def test_server_keeps_serving_during_a_cold_load_and_fuses_concurrent_jobs(pm, o
             srv.wait(timeout=30)
         except Exception:
             srv.kill()
+
+
+def test_match_stage_plain_invocation_with_eight_ranks(pm, oracle, tmp_path):
+    """`python -m phylign_amd.match_stage --gpus 8` without a launcher starts its own 8 ranks (here sharing the one GPU
+    over gloo); the fixture has 5 batches, so three ranks hold none -- they still take part in the gather -- and the 5
+    files and the 04_filter FASTA are the one-rank run's"""
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT, PHYLIGN_DIST_BACKEND="gloo", PHYLIGN_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--gpus", "8",
+                        "--batches", str(tmp_path / "batches.txt"), "--cobs-dir", str(tmp_path / "cobs"),
+                        "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"),
+                        "--out-dir", str(tmp_path / "03_match"), "--nb-best-hits", "3",
+                        "--filter-out", str(tmp_path / "04_filter" / "Q.fa")], capture_output=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    import json
+    reports = [json.loads(ln) for ln in r.stderr.decode().splitlines() if ln.startswith("{") and '"world"' in ln]
+    assert sorted(rep["rank"] for rep in reports) == list(range(8)) and all(rep["world"] == 8 for rep in reports)
+    assert sorted(rep["batches"] for rep in reports) == [0, 0, 0, 1, 1, 1, 1, 1]

@@ -373,3 +373,114 @@ def test_long_queries_shared_across_workgroups_at_scale(pm):
                 assert np.array_equal(got, ref), (rnd, split)
     finally:
         pm.set_option("wide_query_split", 0)
+
+
+def test_query_parts_of_an_index_partition_the_search(pm, oracle):
+    """pm_search_async_parts: an index searched with the query shares [0, a), [a, b), [b, den) -- as the ranks that
+    hold a copy of it would -- yields, put together, exactly the records of the whole search; other indexes of the same
+    search are untouched.  Narrow rows (mixed-width launch), one width only (uniform launch), 512-byte rows, rows wider
+    than 1024 bytes (column slabs), a compact-like second hash function, queries of four counter-width classes, both
+    scan modes, the n-best cut, and the wide-query form."""
+    rng = np.random.default_rng(4242)
+    lens = [31, 33, 36] * 5 + [150] * 41 + [158, 200, 700] * 6 + [1053, 1500, 4000] * 3
+    rng.shuffle(lens)
+    queries = [(f"p{i}", rand_seq(rng, int(L))) for i, L in enumerate(lens)]
+    nq = len(queries)
+    cases = []
+    for n_docs, S, nh in ((200, 3000, 1), (664, 4000, 1), (1000, 2000, 2), (4000, 1500, 1), (9001, 600, 1)):
+        plant = [(qi, int(rng.integers(0, n_docs)), fr) for qi in range(nq) for fr in (1.0, 0.8, 0.7, 0.69)]
+        index, fasta, _ = build_case(oracle, rng, n_docs, S, queries, num_hashes=nh, density=0.1, plant=plant)
+        cases.append((index, pm.Index.load_mem(index, layout=int(rng.integers(0, 3)))))
+    q = pm.Queries(fasta)
+    den = 1024
+    cuts = [(0, den), (0, 1, den), (0, 300, 777, den), (0, 512, 513, den), (0, den - 1, den)]
+
+    def run(ixs, parts, thr, n):
+        res = pm.search_async(ixs, q, thr, nb_best_hits=n, parts=parts)
+        h = res.hits()
+        launches = res.launches()
+        res.free()
+        return h, launches
+    try:
+        for bound in (1, 0):
+            pm.set_option("threshold_bound", bound)
+            for wq in (0, 1):
+                pm.set_option("wide_query", wq)
+                for sel in ([0, 1, 2], [1], [3], [4], [0, 1, 2, 3, 4]):           # mixed / uniform narrow / 512 B / slabs / all
+                    ixs = [cases[i][1] for i in sel]
+                    for thr, n in ((0.7, 0), (0.7, 2), (0.0, 0)):
+                        whole, lw = run(ixs, None, thr, n)
+                        alg_whole = sum(L["algorithmic_bytes"] for L in lw)
+                        for target in range(len(ixs)):
+                            for cut in cuts[1:] if len(ixs) < 5 else cuts[2:3]:
+                                got, alg = [], 0
+                                for lo, hi in zip(cut[:-1], cut[1:]):
+                                    parts = [None] * len(ixs)
+                                    parts[target] = (lo, hi, den)
+                                    h, ll = run(ixs, parts, thr, n)
+                                    got.append(h[h["slot"] == target])
+                                    alg += sum(L["algorithmic_bytes"] for L in ll)
+                                    others = h[h["slot"] != target]
+                                    assert np.array_equal(others, whole[whole["slot"] != target])
+                                merged = pm.sort_hits(np.ascontiguousarray(np.concatenate(got)))
+                                assert np.array_equal(merged, whole[whole["slot"] == target]), (bound, wq, sel, thr, n, target, cut)
+                                # bytes: the target's rows are counted once over its parts, the others' once per search
+                                k = len(cut) - 1
+                                tb = int(ixs[target].info.row_bytes) * int(ixs[target].info.num_hashes) * q.count()[1]
+                                assert alg == alg_whole * k - tb * (k - 1)
+        # the text of the put-together records is the oracle's
+        index, ix = cases[1]
+        a, _ = run([ix], [(0, 400, den)], 0.7, 0)
+        b, _ = run([ix], [(400, den, den)], 0.7, 0)
+        both = pm.sort_hits(np.ascontiguousarray(np.concatenate([a, b])))
+        assert pm.format_hits(ix, q, both) == oracle.query_file(index, fasta, 0.7)
+        with pytest.raises(pm.PMError):
+            pm.search_async([ix], q, 0.7, parts=[(5, 4, den)])
+        with pytest.raises(pm.PMError):
+            pm.search_async([ix], q, 0.7, parts=[(0, den + 1, den)])
+    finally:
+        pm.set_option("threshold_bound", 1)
+        pm.set_option("wide_query", 0)
+
+
+def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
+    """`python bench.py --gpus 8` exactly as the driver types it (no launcher): the script starts its own 8 ranks --
+    here sharing the one GPU over gloo -- with a few small batches resident on two ranks that share their queries;
+    the gathered records equal the one-rank run's, and so do those of the 305-batch full_collection leg"""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    common = ["--steps", "2", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline"]
+    one = tmp_path / "one.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(one), "--only-headline"],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    eight, fullc = tmp_path / "eight.npy", tmp_path / "fullc.npy"
+    env8 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_FULL_MIN_WORLD="8")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + common +
+                       ["--dump-hits", str(eight), "--dump-full-hits", str(fullc)], capture_output=True, env=env8)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    part = line["participants"]
+    assert line["n_gpus"] == 8 and part["ranks"] == 8 and len(part["rank_ms_per_step"]) == 8 and len(part["rank_host_ms"]) == 8
+    shared = line["config"]["batches_on_two_ranks"]
+    assert 1 <= len(shared) <= 7 and all(len(s["query_shares"]) == 2 for s in shared)
+    assert sum(part["rank_batches"]) == 64 + len(shared) and min(part["rank_batches"]) >= 1
+    assert line["threshold_bound"]["hits_identical_to_headline"]
+    a, b = np.load(one), np.load(eight)
+    assert len(a) > 50 and np.array_equal(a, b)
+    fc = line["full_collection"]
+    assert fc["hits_identical"] and sum(fc["rank_batches"]) == 305 and len(fc["fetch_all_rows"]["rank_ms_per_step"]) == 8
+    whole = tmp_path / "whole.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "full", "--only-headline"] + common +
+                       ["--dump-hits", str(whole)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert np.array_equal(np.load(fullc), np.load(whole))
+    # whole batches only (--no-replicas): the same records again
+    plain = tmp_path / "plain.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-replicas", "--only-headline"] + common +
+                       ["--dump-hits", str(plain)], capture_output=True, env=env8)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert np.array_equal(np.load(plain), a)

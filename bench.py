@@ -174,9 +174,10 @@ def main():
     ap.add_argument("--clustered-multi", action="store_true",
                     help="run the clustered variant with N > 1 too (it ships ~0.5 GB of records per step to rank 0; "
                          "by default it is a single-GPU figure)")
-    ap.add_argument("--no-replicas", action="store_true",
-                    help="N > 1: whole batches only (by default a few small batches are resident on two ranks that share their "
-                         "queries, which levels the ranks' scan work)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: level the ranks' scan work by making a few small batches resident on two ranks that share their "
+                         "queries (workload.assign_parts / pm_search_async_parts).  Off by default: on the 64 batches of config 3 "
+                         "whole batches already balance 8 ranks to within the run-to-run noise (profiles/r04/NOTES.md)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queueing the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=24.0, help="timed CPU work of the baseline (2 partitions x 3 runs)")
@@ -244,10 +245,10 @@ def main():
         shapes = W.scale_shapes(shapes, args.rows_divisor)
     nparts = args.emulate_world if (args.emulate_world and world == 1) else world
     # static batch -> rank map; a few small batches are resident on two ranks that share their queries (assign_parts)
-    if args.no_replicas:
-        pparts = [[(p_, 0, W.PART_DEN) for p_ in part] for part in W.assign_batches(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))]
-    else:
+    if args.replicas:
         pparts = W.assign_parts(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))
+    else:
+        pparts = [[(p_, 0, W.PART_DEN) for p_ in part] for part in W.assign_batches(shapes, nparts, capacity_bytes=int(dev["hbm_total"] * 0.85))]
     parts = [[p_ for p_, _, _ in part] for part in pparts]
     base = 0
     bases = []
@@ -831,7 +832,7 @@ def main():
     if rank == 0 and args.dump_hits and run_head["hits"] is not None:
         # slots are numbered rank-major; name every record by its batch (position in the shape list)
         # and re-order, so that runs with different shardings can be compared record by record
-        pos_of_slot = np.zeros(len(shapes), dtype=np.uint32)
+        pos_of_slot = np.zeros(sum(len(p_) for p_ in parts), dtype=np.uint32)     # (a batch on two ranks has two slots)
         for r in range(nparts):
             for i, pos in enumerate(parts[r]):
                 pos_of_slot[bases[r] + i] = pos

@@ -116,8 +116,10 @@ def assign_batches(shapes, n_ranks, capacity_bytes=None):
 
 
 PART_DEN = 1024          # query shares are expressed in 1/1024 of the query set (pm_qpart_t.den)
-# the part of scan_cost a batch costs whatever share of the queries it is searched with
-_BATCH_FIXED = int(os.environ.get("PHYLIGN_BATCH_FIXED", "25"))
+# the part of scan_cost a batch costs whatever share of the queries it is searched with.  Measured on one MI355X
+# (profiles/r04/NOTES.md): none that the run-to-run noise lets one see -- ranks with 9-10 batches of an 8-way split of
+# config 3 finish with those that hold 7-8.
+_BATCH_FIXED = int(os.environ.get("PHYLIGN_BATCH_FIXED", "0"))
 
 
 def assign_parts(shapes, n_ranks, capacity_bytes=None, max_replica_bytes=4 << 30, tolerance=0.004):

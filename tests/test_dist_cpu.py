@@ -141,7 +141,7 @@ def test_loader_admission_is_in_submission_order_and_never_deadlocks():
 
 def test_eight_way_partition_of_config3_is_balanced_on_measured_batch_times():
     """the static batch -> GPU map of bench.py --gpus 8 (workload.assign_batches on line-cost weights) priced with the
-    per-batch scan times MEASURED on one MI355X (profiles/r03/per_batch_cost.tsv): slowest rank / mean <= 1.05 in
+    per-batch scan times MEASURED on one MI355X (profiles/r03/per_batch_cost.tsv): slowest rank / mean <= 1.025 in
     both scan modes, for 2, 4 and 8 ranks -- the bound on strong-scaling efficiency that the partition itself costs"""
     import os
     from phylign_amd import workload as W
@@ -159,7 +159,7 @@ def test_eight_way_partition_of_config3_is_balanced_on_measured_batch_times():
         assert sorted(i for p in parts for i in p) == list(range(64))
         for mode in (0, 1):
             loads = [sum(cost[shapes[i].batch][mode] for i in p) for p in parts]
-            assert max(loads) / (sum(loads) / n) <= 1.05, (n, mode, loads)
+            assert max(loads) / (sum(loads) / n) <= 1.025, (n, mode, loads)
 
 
 def test_assign_batches_invariants_on_random_collections():
@@ -198,7 +198,8 @@ def test_effective_cpus_is_positive_and_bounded():
 def test_assign_parts_shares_partition_every_batch_and_level_the_ranks():
     """workload.assign_parts: every batch is whole on one rank or shared by exactly two whose query shares tile
     [0, PART_DEN); replicas are small batches within the capacity; priced with the per-batch scan times MEASURED on one
-    MI355X (a share costs that share of the batch's time) the slowest of 8 ranks is within 2 % of the mean"""
+    MI355X in launches of their own (a share costs that share of the batch's time) the slowest of 8 ranks is within 3 % of
+    the mean (in the fused launches of a real step the ranks of both partitions end within ~1 %: profiles/r04/NOTES.md)"""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cost = {}
@@ -229,7 +230,7 @@ def test_assign_parts_shares_partition_every_batch_and_level_the_ranks():
         if n in (2, 4, 8):
             for mode in (0, 1):
                 loads = [sum(cost[shapes[p].batch][mode] * (hi - lo) / W.PART_DEN for p, lo, hi in part) for part in parts]
-                assert max(loads) / (sum(loads) / n) <= 1.02, (n, mode, loads)
+                assert max(loads) / (sum(loads) / n) <= 1.03, (n, mode, loads)
     # capacity: a replica never pushes a rank over it
     full = W.select("full")
     cap = int(288e9 * 0.85)

@@ -445,7 +445,7 @@ def test_query_parts_of_an_index_partition_the_search(pm, oracle):
 
 def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
     """`python bench.py --gpus 8` exactly as the driver types it (no launcher): the script starts its own 8 ranks --
-    here sharing the one GPU over gloo -- with a few small batches resident on two ranks that share their queries;
+    here sharing the one GPU over gloo -- with a few small batches resident on two ranks that share their queries (--replicas);
     the gathered records equal the one-rank run's, and so do those of the 305-batch full_collection leg"""
     import json
     env = dict(os.environ, PYTHONPATH=ROOT)
@@ -457,7 +457,7 @@ def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     eight, fullc = tmp_path / "eight.npy", tmp_path / "fullc.npy"
     env8 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_FULL_MIN_WORLD="8")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + common +
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--replicas"] + common +
                        ["--dump-hits", str(eight), "--dump-full-hits", str(fullc)], capture_output=True, env=env8)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
@@ -478,9 +478,9 @@ def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
                        ["--dump-hits", str(whole)], capture_output=True, env=env)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert np.array_equal(np.load(fullc), np.load(whole))
-    # whole batches only (--no-replicas): the same records again
+    # whole batches only (the default): the same records again
     plain = tmp_path / "plain.npy"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-replicas", "--only-headline"] + common +
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--only-headline"] + common +
                        ["--dump-hits", str(plain)], capture_output=True, env=env8)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert np.array_equal(np.load(plain), a)

@@ -196,6 +196,14 @@ int  pm_queries_count(const pm_queries_t* q, uint64_t* n_queries, uint64_t* n_te
 /* number of k-mers of record i (length - k + 1) */
 int  pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_terms);
 void pm_queries_free(pm_queries_t* q);
+/* Frees the HBM copies of the query set (sequences, descriptors, hash buffers: about 8 bytes per k-mer and hash function)
+ * and keeps the host side -- names and sequences, which results, texts and the 04_filter merge refer to.  The next search
+ * uploads them again.  For a query file searched chunk after chunk (pm_fasta_record_cuts): a chunk that is not searched
+ * for a while need not stay resident.  Waits only for searches that were queued with THIS set. */
+int  pm_queries_release_device(pm_queries_t* q);
+/* *resident: HBM bytes the set holds now; *when_searched: what it holds while searched against indexes of num_hashes
+ * hash functions (either may be NULL) */
+int  pm_queries_device_bytes(const pm_queries_t* q, uint32_t num_hashes, uint64_t* resident, uint64_t* when_searched);
 /* runs the canonicalise+XXH64 kernel and copies hashes[term*num_hashes + j]
  * (dense, FASTA order) to the host: parity hook for SURVEY row a5 */
 int  pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out);
@@ -329,7 +337,9 @@ int  pm_merge_add_piece(pm_merge_t* m, int64_t piece, const char* batch, const p
  * "*<qname>[ comment]\t<N>" starts a query, every other non-empty line is "<rnd>_<ref> <kmers>" (two fields,
  * exactly one '_'); a malformed line, a text without header and a query that is not in the query file fail
  * with PM_EINVAL like the reference raises (match lines ahead of the first header join the first query, as
- * they do there). */
+ * they do there).  Lines end at "\n", "\r\n" or a lone "\r" (the reference reads in text mode).  Counts are kept as 32 bits:
+ * a k-mer count above 2^32 - 1 (Python's int() takes any; no read has that many k-mers) counts as 2^32 - 1.
+ * Safe to call while other threads add or extend the same merge. */
 int  pm_merge_add_text(pm_merge_t* m, const char* batch, const char* text, size_t len);
 /* What the merge holds so far, as hit records {query (numbered through the whole file), doc, score, slot = number of
  * the batch in this merge: pm_merge_batches} ordered by (slot, query, score desc, doc asc): one rank's share of the

@@ -80,6 +80,8 @@ SYMBOLS = [
     ("pm_queries_count", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pm_queries_terms", C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("pm_queries_free", None, [_P]),
+    ("pm_queries_release_device", C.c_int, [_P]),
+    ("pm_queries_device_bytes", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pm_hash_terms", C.c_int, [_P, C.c_int, C.c_uint32, _P]),
     ("pm_search", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("pm_search_async", C.c_int, [C.POINTER(_P), C.c_size_t, _P, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
@@ -364,6 +366,16 @@ class Queries:
         out = np.zeros(nt * num_hashes, dtype=np.uint64)
         _chk(load().pm_hash_terms(self._h, canonicalize, num_hashes, out.ctypes.data))
         return out
+
+    def release_device(self):
+        """frees the HBM copies (sequences, descriptors, hashes); the host side stays, the next search uploads again"""
+        _chk(load().pm_queries_release_device(self._h))
+
+    def device_bytes(self, num_hashes=1):
+        """(HBM bytes held now, HBM bytes held while searched with num_hashes hash functions)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(load().pm_queries_device_bytes(self._h, num_hashes, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def free(self):
         if self._h:

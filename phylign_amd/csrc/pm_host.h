@@ -51,6 +51,12 @@ int fail(int code, const char* fmt, ...);
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);             \
     } while (0)
 
+// No C++ exception crosses the C ABI: every `extern "C" int` entry point is a function-try-block that ends in
+// PM_GUARD_END, which turns whatever was thrown (std::bad_alloc from a vector or string of a huge input, on the calling
+// thread or on a pool thread: parallel_for hands it over) into an error code + pm_last_error().
+int on_exception();          // call inside a catch block
+#define PM_GUARD_END catch (...) { return on_exception(); }
+
 struct HitBuf { uint4* p; uint64_t cap; };
 struct PinBuf { void* p; size_t bytes; };
 // Per-search scratch that must stay untouched while the search is in flight (several
@@ -143,10 +149,11 @@ struct pm_queries {
     struct HashBuf { int canon; uint32_t nh; uint64_t* d; uint64_t epoch; };
     std::vector<HashBuf> hashes;
     uint64_t epoch = 0;
+    hipEvent_t last_use = nullptr;          // recorded behind the last search queued with this set (pm_queries_release_device)
 };
 
 // pm_runtime.cpp: fn(0) ... fn(n - 1) on the library's persistent worker threads (and the caller's); returns when all
-// are done.  Host-side work (text formatting, deflate, FASTA emit, query parsing) used to start its own std::threads per
+// are done; an exception thrown by fn on any thread is rethrown here (the first one), after every item has run.  Host-side work (text formatting, deflate, FASTA emit, query parsing) used to start its own std::threads per
 // call: thousands of short-lived threads leave glibc one malloc arena each (RSS grew by ~7 MB per stage run on a 256-CPU
 // box, tools/leak_check_stage.py); pooled threads keep their arenas.  fn must not call parallel_for itself.
 void parallel_for(size_t n, const std::function<void(size_t)>& fn);

@@ -263,7 +263,8 @@ void release_stage_pool() {                    // pm_shutdown
 
 static int stream_matrix_file(int fd, uint64_t file_off, pm_index* ix, uint64_t rb, uint64_t S) {
     const uint64_t stride = ix->info.stride;
-    const uint64_t chunk_rows = std::max<uint64_t>(1, (32ull << 20) / rb);
+    if (rb > kStageBytes) return fail(PM_ERANGE, "row of %llu bytes is wider than a staging chunk", (unsigned long long)rb);
+    const uint64_t chunk_rows = std::max<uint64_t>(1, kStageBytes / rb);
     const uint64_t n_chunks = (S + chunk_rows - 1) / chunk_rows;
     int want = 6;                                               // PM_LOAD_THREADS: readers per index file
     if (const char* env = getenv("PM_LOAD_THREADS")) want = std::max(1, std::min(32, atoi(env)));
@@ -400,7 +401,10 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
                     (unsigned long long)size_hint, (unsigned long long)(h.data_off + S * rb));
         struct stat fst;
         const off_t pos = (rd.fd >= 0 && !rd.mem) ? lseek(rd.fd, 0, SEEK_CUR) : (off_t)-1;
-        if (pos >= (off_t)head.size() && fstat(rd.fd, &fst) == 0 && S_ISREG(fst.st_mode) && S * rb >= (256ull << 20)) {
+        // (a row wider than one pooled staging chunk -- more than 2^28 documents -- takes the serial path, whose buffers
+        // are sized to the row)
+        if (pos >= (off_t)head.size() && fstat(rd.fd, &fst) == 0 && S_ISREG(fst.st_mode) && S * rb >= (256ull << 20) &&
+            rb <= kStageBytes) {
             // seekable: several readers in parallel (the index began at pos - head.size() of the file)
             rc = stream_matrix_file(rd.fd, (uint64_t)(pos - (off_t)head.size()) + h.data_off, ix, rb, S);
         } else {
@@ -469,13 +473,13 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
     return PM_OK;
 }
 
-extern "C" int pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out) {
+extern "C" int pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out) try {
     NEED_DEV();
     if (!out || fd < 0) return fail(PM_EINVAL, "bad argument");
     Reader rd; rd.fd = fd;
     return load_from_reader(rd, size_hint, layout, false, out);
-}
-extern "C" int pm_index_load_file(const char* path, uint64_t size_hint, int layout, pm_index_t** out) {
+} PM_GUARD_END
+extern "C" int pm_index_load_file(const char* path, uint64_t size_hint, int layout, pm_index_t** out) try {
     NEED_DEV();
     if (!path || !out) return fail(PM_EINVAL, "bad argument");
     int fd = open(path, O_RDONLY);
@@ -483,24 +487,24 @@ extern "C" int pm_index_load_file(const char* path, uint64_t size_hint, int layo
     int rc = pm_index_load_fd(fd, size_hint, layout, out);
     close(fd);
     return rc;
-}
-extern "C" int pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out) {
+} PM_GUARD_END
+extern "C" int pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out) try {
     NEED_DEV();
     if (!buf || !out) return fail(PM_EINVAL, "bad argument");
     Reader rd; rd.mem = (const uint8_t*)buf; rd.mem_len = len;
     return load_from_reader(rd, 0, layout, false, out);
-}
-extern "C" int pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out) {
+} PM_GUARD_END
+extern "C" int pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out) try {
     if (!buf || !out) return fail(PM_EINVAL, "bad argument");
     Reader rd; rd.mem = (const uint8_t*)buf; rd.mem_len = len;
     return load_from_reader(rd, 0, PM_LAYOUT_COMPACT, true, out);
-}
+} PM_GUARD_END
 
 // An index made in place instead of read from a file: header fields + document names + a ZEROED matrix in HBM (or, with
 // header_only, names only).  Whoever builds signatures on the device fills the matrix through pm_index_matrix_device.
 extern "C" int pm_index_create(uint32_t term_size, uint32_t canonicalize, uint64_t signature_size, uint32_t num_hashes,
                                const char* names, size_t names_len, uint32_t n_docs, int layout, int header_only,
-                               pm_index_t** out) {
+                               pm_index_t** out) try {
     if (!out || n_docs == 0 || signature_size == 0 || num_hashes == 0 || term_size == 0 || (!names && names_len))
         return fail(PM_EINVAL, "bad index shape");
     if (!header_only) NEED_DEV();
@@ -518,28 +522,28 @@ extern "C" int pm_index_create(uint32_t term_size, uint32_t canonicalize, uint64
     }
     *out = named;
     return PM_OK;
-}
+} PM_GUARD_END
 // The resident matrix of a classic index for code that shares the device with the library (kernels of its own that
 // build or inspect signatures): row r starts at dptr + r * stride, document d is bit d % 8 of byte d / 8.
-extern "C" int pm_index_matrix_device(const pm_index_t* ix, void** dptr, uint64_t* stride) {
+extern "C" int pm_index_matrix_device(const pm_index_t* ix, void** dptr, uint64_t* stride) try {
     if (!ix || !dptr || !stride) return fail(PM_EINVAL, "bad argument");
     if (!ix->d_matrix) return fail(PM_EINVAL, "index has no single resident matrix (header-only, dropped, or a compact index)");
     *dptr = ix->d_matrix; *stride = ix->info.stride;
     return PM_OK;
-}
+} PM_GUARD_END
 
 // Copies rows [row0, row0 + n) (row_bytes each, file layout) back to the host: lets a test
 // rebuild the .cobs_classic file of a synthetic / planted index for the oracle.
-extern "C" int pm_index_read_rows(const pm_index_t* ix, uint64_t row0, uint64_t n, void* out) {
+extern "C" int pm_index_read_rows(const pm_index_t* ix, uint64_t row0, uint64_t n, void* out) try {
     NEED_DEV();
     if (!ix || !ix->d_matrix || !out || row0 + n > ix->info.signature_size) return fail(PM_EINVAL, "bad argument");
     if (n == 0) return PM_OK;
     HIPCHK(hipMemcpy2D(out, ix->info.row_bytes, ix->d_matrix + row0 * ix->info.stride, ix->info.stride,
                        ix->info.row_bytes, n, hipMemcpyDeviceToHost));
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_docs, uint32_t term_size, pm_index_t** out) {
+extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_docs, uint32_t term_size, pm_index_t** out) try {
     if ((!names && len) || !out) return fail(PM_EINVAL, "bad argument");
     pm_index* ix = new pm_index();
     ix->info.term_size = term_size; ix->info.n_docs = n_docs; ix->info.row_bytes = ((uint64_t)n_docs + 7) / 8;
@@ -557,34 +561,34 @@ extern "C" int pm_index_from_names(const char* names, size_t len, uint32_t n_doc
     ix->name_off[n_docs] = ix->names_blob.size();
     *out = ix;
     return PM_OK;
-}
-extern "C" int pm_index_drop_matrix(pm_index_t* ix) {
+} PM_GUARD_END
+extern "C" int pm_index_drop_matrix(pm_index_t* ix) try {
     if (!ix) return fail(PM_EINVAL, "bad argument");
     bind_thread_quiet();
     if (ix->d_matrix) { (void)hipFree(ix->d_matrix); ix->d_matrix = nullptr; }
     for (pm_index* p : ix->parts) pm_index_drop_matrix(p);
     ix->info.has_matrix = 0; ix->info.device_bytes = 0;
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_index_info(const pm_index_t* ix, pm_index_info_t* info) {
+extern "C" int pm_index_info(const pm_index_t* ix, pm_index_info_t* info) try {
     if (!ix || !info) return fail(PM_EINVAL, "bad argument");
     *info = ix->info;
     return PM_OK;
-}
+} PM_GUARD_END
 extern "C" const char* pm_index_doc_name(const pm_index_t* ix, uint32_t doc, size_t* len) {
     if (!ix || doc >= ix->info.n_docs) return nullptr;
     if (len) *len = (size_t)(ix->name_off[doc + 1] - ix->name_off[doc] - 1);
     return ix->names_blob.data() + ix->name_off[doc];
 }
-extern "C" int pm_index_read_row(const pm_index_t* ix, uint64_t row, void* out) {
+extern "C" int pm_index_read_row(const pm_index_t* ix, uint64_t row, void* out) try {
     NEED_DEV();
     if (!ix || !ix->d_matrix || !out || row >= ix->info.signature_size) return fail(PM_EINVAL, "bad argument");
     HIPCHK(hipMemcpy(out, ix->d_matrix + row * ix->info.stride, ix->info.row_bytes, hipMemcpyDeviceToHost));
     return PM_OK;
-}
+} PM_GUARD_END
 // GPU that holds the signature matrix (hipPointerGetAttributes); -1 for header-only handles
-extern "C" int pm_index_device(const pm_index_t* ix, int* device) {
+extern "C" int pm_index_device(const pm_index_t* ix, int* device) try {
     if (!ix || !device) return fail(PM_EINVAL, "bad argument");
     const uint8_t* p = ix->d_matrix;
     if (!p) for (const pm_index* part : ix->parts) if (part->d_matrix) { p = part->d_matrix; break; }
@@ -594,7 +598,7 @@ extern "C" int pm_index_device(const pm_index_t* ix, int* device) {
     HIPCHK(hipPointerGetAttributes(&at, p));
     *device = at.device;
     return PM_OK;
-}
+} PM_GUARD_END
 extern "C" void pm_index_free(pm_index_t* ix) {
     if (!ix) return;
     bind_thread_quiet();

@@ -99,7 +99,7 @@ static int parse_cobs_range(pm_queries* q, const char* fasta, size_t begin, size
 // Offsets at which a prepared query file (records start with '>' or ';' at a line start) is cut into pieces of
 // `max_records` records: what match_stage --query-chunk needs for a file of more reads than fit HBM at once.  Record
 // starts are counted on several threads, then the cuts are located inside the pieces that hold them.
-extern "C" int pm_fasta_record_cuts(const char* fasta, size_t len, uint64_t max_records, uint64_t** cuts, uint64_t* n_cuts) {
+extern "C" int pm_fasta_record_cuts(const char* fasta, size_t len, uint64_t max_records, uint64_t** cuts, uint64_t* n_cuts) try {
     if ((!fasta && len) || !cuts || !n_cuts) return fail(PM_EINVAL, "bad argument");
     *cuts = nullptr; *n_cuts = 0;
     if (max_records == 0 || len == 0) return PM_OK;
@@ -140,9 +140,9 @@ extern "C" int pm_fasta_record_cuts(const char* fasta, size_t len, uint64_t max_
     memcpy(buf, out.data(), out.size() * sizeof(uint64_t));
     *cuts = buf; *n_cuts = out.size();
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) {
+extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_size, pm_queries_t** out) try {
     if ((!fasta && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
     pm_queries* q = new pm_queries();
     q->k = term_size;
@@ -202,7 +202,7 @@ extern "C" int pm_queries_parse(const char* fasta, size_t len, uint32_t term_siz
     if (rc != PM_OK) { delete q; return rc; }
     *out = q;
     return PM_OK;
-}
+} PM_GUARD_END
 
 // Rules `fix_query` + `concatenate_queries` (Snakefile:314-352) fused into the parser: what
 //   seqtk seq -A -U -C in | awk '{if(NR%2==1){print $0;}else{gsub(/[^ACGT]/, "A"); print;}}'
@@ -291,7 +291,7 @@ static int parse_raw_normalised(pm_queries* q, const char* buf, size_t len) {
     return PM_OK;
 }
 
-extern "C" int pm_queries_parse_raw(const char* buf, size_t len, uint32_t term_size, int normalise, pm_queries_t** out) {
+extern "C" int pm_queries_parse_raw(const char* buf, size_t len, uint32_t term_size, int normalise, pm_queries_t** out) try {
     if (!normalise) return pm_queries_parse(buf, len, term_size, out);
     if ((!buf && len) || !out || term_size == 0) return fail(PM_EINVAL, "bad argument");
     pm_queries* q = new pm_queries();
@@ -301,10 +301,10 @@ extern "C" int pm_queries_parse_raw(const char* buf, size_t len, uint32_t term_s
     if (rc != PM_OK) { delete q; return rc; }
     *out = q;
     return PM_OK;
-}
+} PM_GUARD_END
 
 // ">header\nSEQUENCE\n" per record: the prepared query file (intermediate/01_queries_merged/*.fa) this set stands for
-extern "C" int pm_queries_fasta(const pm_queries_t* q, char** text, size_t* len) {
+extern "C" int pm_queries_fasta(const pm_queries_t* q, char** text, size_t* len) try {
     if (!q || !text || !len) return fail(PM_EINVAL, "bad argument");
     size_t total = 0;
     for (size_t i = 0; i < q->headers.size(); ++i) total += q->headers[i].size() + 3 + (size_t)(q->seq_off[i + 1] - q->seq_off[i]);
@@ -322,31 +322,67 @@ extern "C" int pm_queries_fasta(const pm_queries_t* q, char** text, size_t* len)
     buf[o] = 0;
     *text = buf; *len = o;
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_queries_count(const pm_queries_t* q, uint64_t* n_queries, uint64_t* n_terms) {
+extern "C" int pm_queries_count(const pm_queries_t* q, uint64_t* n_queries, uint64_t* n_terms) try {
     if (!q) return fail(PM_EINVAL, "bad argument");
     if (n_queries) *n_queries = q->headers.size();
     if (n_terms) *n_terms = q->total_terms;
     return PM_OK;
-}
-extern "C" int pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_terms) {
+} PM_GUARD_END
+extern "C" int pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_terms) try {
     if (!q || i >= q->n_terms.size() || !n_terms) return fail(PM_EINVAL, "bad argument");
     *n_terms = q->n_terms[(size_t)i];
     return PM_OK;
-}
-extern "C" void pm_queries_free(pm_queries_t* q) {
-    if (!q) return;
-    bind_thread_quiet();
-    if (g_ctx.ready && q->on_device) (void)hipStreamSynchronize(g_ctx.stream);   // a search in flight may still read them
+} PM_GUARD_END
+static void drop_device_state(pm_queries* q) {
     if (q->d_seq) (void)hipFree(q->d_seq);
     if (q->d_qd) (void)hipFree(q->d_qd);
     if (q->d_blkq) (void)hipFree(q->d_blkq);
     if (q->d_qmap) (void)hipFree(q->d_qmap);
     if (q->d_thr) (void)hipFree(q->d_thr);
     for (auto& h : q->hashes) if (h.d) (void)hipFree(h.d);
+    q->d_seq = nullptr; q->d_qd = nullptr; q->d_blkq = nullptr; q->d_qmap = nullptr; q->d_thr = nullptr;
+    q->thr_for = -1.0;
+    q->hashes.clear();
+    q->on_device = false;
+}
+extern "C" void pm_queries_free(pm_queries_t* q) {
+    if (!q) return;
+    bind_thread_quiet();
+    if (g_ctx.ready && q->on_device) (void)hipStreamSynchronize(g_ctx.stream);   // a search in flight may still read them
+    drop_device_state(q);
+    if (q->last_use) (void)hipEventDestroy(q->last_use);
     delete q;
 }
+// Frees the HBM copies of the query set (sequences, descriptors, per-query thresholds, hash buffers: ~8 bytes per k-mer
+// and hash function) and keeps everything on the host -- names and sequences, which results, texts and the 04_filter merge
+// refer to.  The next search uploads them again.  For a query file that is searched chunk after chunk: a chunk that is
+// not searched for a while need not stay resident.  Waits only for the searches that use THIS query set.
+extern "C" int pm_queries_release_device(pm_queries_t* q) try {
+    if (!q) return fail(PM_EINVAL, "bad argument");
+    if (!q->on_device) return PM_OK;
+    NEED_DEV();
+    if (q->last_use) HIPCHK(hipEventSynchronize(q->last_use));
+    else HIPCHK(hipStreamSynchronize(g_ctx.stream));
+    drop_device_state(q);
+    return PM_OK;
+} PM_GUARD_END
+// *resident: HBM bytes the query set holds right now; *when_searched: what it holds while it is searched against indexes
+// of num_hashes hash functions (budgeting: match_stage keeps this out of the index admission budget)
+extern "C" int pm_queries_device_bytes(const pm_queries_t* q, uint32_t num_hashes, uint64_t* resident, uint64_t* when_searched) try {
+    if (!q || num_hashes == 0) return fail(PM_EINVAL, "bad argument");
+    const uint64_t nq = q->headers.size();
+    const uint64_t base = q->seqs.size() + 64 + nq * sizeof(QDesc) + std::max<uint64_t>(q->blkq.size(), 1) * 4 + nq * 4;
+    if (resident) {
+        uint64_t r = q->on_device && nq ? base : 0;
+        if (q->d_thr) r += nq * 4;
+        for (auto& h : q->hashes) if (h.d) r += q->n_slots * h.nh * 8;
+        *resident = r;
+    }
+    if (when_searched) *when_searched = base + nq * 4 + q->n_slots * (uint64_t)num_hashes * 8;
+    return PM_OK;
+} PM_GUARD_END
 
 int upload_queries(pm_queries* q) {
     if (q->on_device) return PM_OK;
@@ -385,7 +421,7 @@ int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out) {
     return PM_OK;
 }
 
-extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out) {
+extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_hashes, uint64_t* out) try {
     NEED_DEV();
     if (!q || !out || num_hashes == 0) return fail(PM_EINVAL, "bad argument");
     { int urc = upload_queries(q); if (urc) return urc; }
@@ -405,5 +441,5 @@ extern "C" int pm_hash_terms(pm_queries_t* q, int canonicalize, uint32_t num_has
                 out[o++] = padded[(size_t)(((b0 + t / 8) * num_hashes + j) * 8 + (t & 7))];
     }
     return PM_OK;
-}
+} PM_GUARD_END
 

@@ -25,7 +25,14 @@ uint32_t g_wq_split = 0;
 
 // ------------------------------------------------------------- worker pool
 namespace {
-struct Job { const std::function<void(size_t)>* fn; size_t n; std::atomic<size_t> next{0}, done{0}; };
+struct Job {
+    const std::function<void(size_t)>* fn; size_t n; std::atomic<size_t> next{0}, done{0};
+    std::mutex err_mu; std::exception_ptr err;            // the first exception an item threw (rethrown by parallel_for)
+    void run(size_t i) noexcept {
+        try { (*fn)(i); }
+        catch (...) { std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+    }
+};
 struct Pool {
     std::mutex mu;
     std::condition_variable cv, cv_done;
@@ -43,7 +50,7 @@ struct Pool {
             if (i + 1 >= n) jobs.erase(jobs.begin());       // nothing left to claim (or this was the last item)
             if (i >= n) continue;
             lk.unlock();
-            (*j->fn)(i);
+            j->run(i);                                      // never throws: a pool thread has nobody to throw to
             lk.lock();
             // the owner may destroy the job as soon as it sees done == n: it checks under this lock, and `j` is not touched after the add
             if (j->done.fetch_add(1) + 1 == n) cv_done.notify_all();
@@ -68,7 +75,7 @@ size_t parallel_width() {
 }
 void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
     if (n == 0) return;
-    if (n == 1) { fn(0); return; }
+    if (n == 1) { fn(0); return; }                 // (throws straight to the caller)
     Pool& p = pool();
     p.ensure(parallel_width() - 1);
     Job job; job.fn = &fn; job.n = n;
@@ -80,18 +87,29 @@ void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
     for (;;) {                                 // the caller works too
         const size_t i = job.next.fetch_add(1);
         if (i >= n) break;
-        fn(i);
+        job.run(i);
         job.done.fetch_add(1);
     }
-    std::unique_lock<std::mutex> lk(p.mu);
-    for (auto it = p.jobs.begin(); it != p.jobs.end(); ++it) if (*it == &job) { p.jobs.erase(it); break; }   // all items are claimed
-    p.cv_done.wait(lk, [&] { return job.done.load() >= n; });
+    {
+        std::unique_lock<std::mutex> lk(p.mu);
+        for (auto it = p.jobs.begin(); it != p.jobs.end(); ++it) if (*it == &job) { p.jobs.erase(it); break; }   // all items are claimed
+        p.cv_done.wait(lk, [&] { return job.done.load() >= n; });
+    }
+    if (job.err) std::rethrow_exception(job.err);
+}
+
+int on_exception() {
+    try { throw; }
+    catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "out of host memory"); }
+    catch (const std::length_error& e) { return fail(PM_ENOMEM, "out of host memory (%s)", e.what()); }
+    catch (const std::exception& e) { return fail(PM_EINVAL, "internal error: %s", e.what()); }
+    catch (...) { return fail(PM_EINVAL, "internal error: unknown exception"); }
 }
 
 // ------------------------------------------------------------------ runtime
 extern "C" const char* pm_last_error(void) { return g_err.c_str(); }
 
-extern "C" int pm_init(int device) {
+extern "C" int pm_init(int device) try {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -111,7 +129,7 @@ extern "C" int pm_init(int device) {
     g_ctx.device = device;
     g_ctx.ready = true;
     return PM_OK;
-}
+} PM_GUARD_END
 
 extern "C" void pm_shutdown(void) {
     if (!g_ctx.ready) return;
@@ -139,7 +157,7 @@ extern "C" void pm_shutdown(void) {
     g_ctx = Ctx();
 }
 
-extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus) {
+extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus) try {
     NEED_DEV();
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g_ctx.device));
@@ -150,11 +168,11 @@ extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint6
     if (hbm_free) *hbm_free = fr;
     if (n_cus) *n_cus = prop.multiProcessorCount;
     return PM_OK;
-}
+} PM_GUARD_END
 
 extern "C" void pm_free(void* p) { free(p); }
 
-extern "C" int pm_set_option(const char* name, int64_t value) {
+extern "C" int pm_set_option(const char* name, int64_t value) try {
     if (!name) return fail(PM_EINVAL, "bad argument");
     if (strcmp(name, "threshold_bound") == 0) { g_threshold_bound = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "count_fetched") == 0) { g_count_fetched = value ? 1u : 0u; return PM_OK; }
@@ -170,7 +188,7 @@ extern "C" int pm_set_option(const char* name, int64_t value) {
         return PM_OK;
     }
     return fail(PM_EINVAL, "unknown option '%s'", name);
-}
+} PM_GUARD_END
 
 // The ONE place that turns `-t` into a minimum score (cobs counts_to_result):
 // ceil(threshold * num_terms) in IEEE double.  config.yaml:20 -> Snakefile:410.

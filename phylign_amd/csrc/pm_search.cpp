@@ -440,6 +440,8 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         desc_off += g.members.size();
     }
     HIPCHK(hipEventRecord(r->ev2, st));
+    if (!q->last_use) HIPCHK(hipEventCreateWithFlags(&q->last_use, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(q->last_use, st));          // nothing queued so far reads the query set's HBM copies after this
     // counters to the host by a one-thread kernel writing mapped pinned memory: no DMA engine on the
     // compute stream, so a large D2H of an earlier result (other stream) never delays this search
     HIPCHK(launch_publish(ws->d_cnt, ws->h_cnt_dev, 4, st));
@@ -452,7 +454,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
 }
 
 static int result_wait_impl(pm_result_t* r);
-extern "C" int pm_result_wait(pm_result_t* r) {
+extern "C" int pm_result_wait(pm_result_t* r) try {
     if (!r) return fail(PM_EINVAL, "bad argument");
     if (!r->pending) return r->failed ? fail(r->failed, "this search failed earlier") : PM_OK;
     NEED_DEV();
@@ -464,7 +466,7 @@ extern "C" int pm_result_wait(pm_result_t* r) {
         result_release(r);
     }
     return rc;
-}
+} PM_GUARD_END
 static int result_wait_impl(pm_result_t* r) {
     for (;;) {
         HIPCHK(hipEventSynchronize(r->ws->done));
@@ -504,13 +506,13 @@ static int result_wait_impl(pm_result_t* r) {
 }
 
 extern "C" int pm_search_async(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
-                               double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
+                               double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) try {
     return pm_search_async_parts(idx, n_idx, q, threshold, nb_best_hits, slot_base, nullptr, out);
-}
+} PM_GUARD_END
 
 extern "C" int pm_search_async_parts(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
                                      double threshold, uint32_t nb_best_hits, uint32_t slot_base,
-                                     const pm_qpart_t* parts, pm_result_t** out) {
+                                     const pm_qpart_t* parts, pm_result_t** out) try {
     NEED_DEV();
     if (!idx || !q || !out || n_idx == 0) return fail(PM_EINVAL, "bad argument");
     if (parts)
@@ -546,10 +548,10 @@ extern "C" int pm_search_async_parts(pm_index_t* const* idx, size_t n_idx, pm_qu
     }
     *out = r;
     return PM_OK;
-}
+} PM_GUARD_END
 
 extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
-                         double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) {
+                         double threshold, uint32_t nb_best_hits, uint32_t slot_base, pm_result_t** out) try {
     pm_result_t* r = nullptr;
     int rc = pm_search_async(idx, n_idx, q, threshold, nb_best_hits, slot_base, &r);
     if (rc) return rc;
@@ -563,7 +565,7 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
     }
     *out = r;
     return PM_OK;
-}
+} PM_GUARD_END
 
 #define RESULT_READY(r)                                            \
     do {                                                           \
@@ -573,27 +575,27 @@ extern "C" int pm_search(pm_index_t* const* idx, size_t n_idx, pm_queries_t* q,
         }                                                          \
     } while (0)
 
-extern "C" int pm_result_stats(const pm_result_t* r, pm_stats_t* st) {
+extern "C" int pm_result_stats(const pm_result_t* r, pm_stats_t* st) try {
     if (!r || !st) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
     *st = r->st;
     return PM_OK;
-}
-extern "C" int pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size_t* n) {
+} PM_GUARD_END
+extern "C" int pm_result_launches(const pm_result_t* r, pm_launch_t* out, size_t cap, size_t* n) try {
     if (!r || !n) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
     *n = r->launches.size();
     if (out) for (size_t i = 0; i < r->launches.size() && i < cap; ++i) out[i] = r->launches[i];
     return PM_OK;
-}
-extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n) {
+} PM_GUARD_END
+extern "C" int pm_result_hits_device(const pm_result_t* r, const void** dptr, uint64_t* n) try {
     if (!r || !dptr || !n) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
     *dptr = r->d_hits; *n = r->n_records;
     return PM_OK;
-}
+} PM_GUARD_END
 static int ensure_ordered(pm_result* r);
-extern "C" int pm_result_copy_hits_device(pm_result_t* r, void* dst, uint64_t capacity, int ordered) {
+extern "C" int pm_result_copy_hits_device(pm_result_t* r, void* dst, uint64_t capacity, int ordered) try {
     NEED_DEV();
     if (!r) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
@@ -608,7 +610,7 @@ extern "C" int pm_result_copy_hits_device(pm_result_t* r, void* dst, uint64_t ca
         HIPCHK(hipStreamSynchronize(g_ctx.d2h_stream));
     }
     return PM_OK;
-}
+} PM_GUARD_END
 
 bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
     if (a.slot != b.slot) return a.slot < b.slot;
@@ -774,16 +776,16 @@ static int ensure_ordered(pm_result* r) {
     return done(PM_OK);
 }
 
-extern "C" int pm_result_ordered_device(pm_result_t* r, const void** dptr, uint64_t* n) {
+extern "C" int pm_result_ordered_device(pm_result_t* r, const void** dptr, uint64_t* n) try {
     NEED_DEV();
     if (!r || !dptr || !n) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
     { int rc = ensure_ordered(r); if (rc) return rc; }
     *dptr = r->d_ord.p; *n = r->n_out;
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_result_hits_into(const pm_result_t* r_, pm_hit_t* out, uint64_t capacity, uint64_t* n_out) {
+extern "C" int pm_result_hits_into(const pm_result_t* r_, pm_hit_t* out, uint64_t capacity, uint64_t* n_out) try {
     NEED_DEV();
     pm_result_t* r = const_cast<pm_result_t*>(r_);
     if (!r || !n_out) return fail(PM_EINVAL, "bad argument");
@@ -798,9 +800,9 @@ extern "C" int pm_result_hits_into(const pm_result_t* r_, pm_hit_t* out, uint64_
     }
     *n_out = r->n_out;
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) {
+extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64_t* n) try {
     NEED_DEV();
     if (!r || !hits || !n) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
@@ -815,12 +817,12 @@ extern "C" int pm_result_hits_host(pm_result_t* r, const pm_hit_t** hits, uint64
     }
     *hits = (const pm_hit_t*)r->host.p; *n = r->n_out;
     return PM_OK;
-}
+} PM_GUARD_END
 // The ordered records of ONE index of the search (slot = its position in the idx array), read back on their own into a
 // pooled pinned buffer: the host half of a stage works batch by batch, and pinning memory for a whole search's records
 // (hundreds of MB at a million reads) costs more than copying them.
 struct pm_slice { PinBuf buf; };
-extern "C" int pm_result_slot_hits(pm_result_t* r, uint32_t slot, const pm_hit_t** hits, uint64_t* n, pm_slice_t** slice) {
+extern "C" int pm_result_slot_hits(pm_result_t* r, uint32_t slot, const pm_hit_t** hits, uint64_t* n, pm_slice_t** slice) try {
     NEED_DEV();
     if (!r || !hits || !n || !slice) return fail(PM_EINVAL, "bad argument");
     RESULT_READY(r);
@@ -837,7 +839,7 @@ extern "C" int pm_result_slot_hits(pm_result_t* r, uint32_t slot, const pm_hit_t
     }
     *hits = (const pm_hit_t*)sl->buf.p; *n = count; *slice = sl;
     return PM_OK;
-}
+} PM_GUARD_END
 extern "C" void pm_slice_free(pm_slice_t* sl) {
     if (!sl) return;
     give_pinned(sl->buf);

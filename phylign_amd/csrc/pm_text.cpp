@@ -170,15 +170,15 @@ static int format_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit
 
 extern "C" int pm_format_hits(const pm_index_t* ix, const pm_queries_t* q,
                               const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
-                              int64_t nb_best, char** text, size_t* len) {
+                              int64_t nb_best, char** text, size_t* len) try {
     return format_impl(ix, q, hits, n_hits, slot, nb_best, 0, text, len);
-}
+} PM_GUARD_END
 // plain cobs text with at most `limit` result lines per query: `cobs query -l limit` (0 = all)
 extern "C" int pm_format_hits_limit(const pm_index_t* ix, const pm_queries_t* q,
                                     const pm_hit_t* hits, uint64_t n_hits, uint32_t slot,
-                                    uint64_t limit, char** text, size_t* len) {
+                                    uint64_t limit, char** text, size_t* len) try {
     return format_impl(ix, q, hits, n_hits, slot, -1, limit, text, len);
-}
+} PM_GUARD_END
 
 // the text in consecutive pieces (one per formatting thread, each ending on a line boundary); the caller hands the
 // pieces back with give_bufs()
@@ -297,7 +297,7 @@ static int deflate_chunks(const std::vector<Chunk>& chunks, int level, std::vect
     for (int rc : zrc) if (rc != Z_OK) { give_bufs(members); return fail(rc == Z_MEM_ERROR ? PM_ENOMEM : PM_EIO, "deflate failed (%d)", rc); }
     return PM_OK;
 }
-extern "C" int pm_gzip_fast(const char* text, size_t len, char** gz, size_t* gz_len) {
+extern "C" int pm_gzip_fast(const char* text, size_t len, char** gz, size_t* gz_len) try {
     if ((!text && len) || !gz || !gz_len) return fail(PM_EINVAL, "bad argument");
     std::vector<Chunk> chunks;
     cut_chunks(text, len, chunks);
@@ -313,7 +313,7 @@ extern "C" int pm_gzip_fast(const char* text, size_t len, char** gz, size_t* gz_
     give_bufs(members);
     *gz = buf; *gz_len = total;
     return PM_OK;
-}
+} PM_GUARD_END
 
 // The 03_match FILE of one batch in one call: what `run_cobs_streaming.sh ... | postprocess_cobs.py -n N | gzip --fast >
 // <batch>____<qfile>.gz` leaves on disk (Snakefile:463-469).  The text is formatted on several threads (as above), cut at
@@ -325,18 +325,18 @@ static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, cons
                                uint64_t* text_bytes, uint64_t* gz_bytes);
 extern "C" int pm_format_hits_gz(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
                                  uint32_t slot, int64_t nb_best, const char* path, int level,
-                                 uint64_t* text_bytes, uint64_t* gz_bytes) {
+                                 uint64_t* text_bytes, uint64_t* gz_bytes) try {
     return format_hits_gz_impl(ix, q, hits, n_hits, slot, nb_best, path, level, 0, text_bytes, gz_bytes);
-}
+} PM_GUARD_END
 // The same for a query set that is searched in CHUNKS (a file of more reads than fit HBM at once): the pieces of a batch's
 // file are written one after the other -- gzip members may simply follow each other -- into "<path>.tmp":
 // piece 1 = first (creates it), 2 = a middle one (appends), 3 = the last (appends, then renames to `path`); 0 = the whole file.
 extern "C" int pm_format_hits_gz_piece(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
                                        uint32_t slot, int64_t nb_best, const char* path, int level, int piece,
-                                       uint64_t* text_bytes, uint64_t* gz_bytes) {
+                                       uint64_t* text_bytes, uint64_t* gz_bytes) try {
     if (piece < 0 || piece > 3) return fail(PM_EINVAL, "piece must be 0 (whole), 1 (first), 2 (middle) or 3 (last)");
     return format_hits_gz_impl(ix, q, hits, n_hits, slot, nb_best, path, level, piece, text_bytes, gz_bytes);
-}
+} PM_GUARD_END
 static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, const pm_hit_t* hits, uint64_t n_hits,
                                uint32_t slot, int64_t nb_best, const char* path, int level, int piece,
                                uint64_t* text_bytes, uint64_t* gz_bytes) {
@@ -377,7 +377,7 @@ static int format_hits_gz_impl(const pm_index_t* ix, const pm_queries_t* q, cons
 }
 
 extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len,
-                             double threshold, int64_t nb_best, char** text, size_t* len) {
+                             double threshold, int64_t nb_best, char** text, size_t* len) try {
     NEED_DEV();
     if (!ix) return fail(PM_EINVAL, "bad argument");
     pm_queries_t* q = nullptr; pm_result_t* r = nullptr;
@@ -394,7 +394,7 @@ extern "C" int pm_query_text(pm_index_t* ix, const char* fasta, size_t fasta_len
     if (r) pm_result_free(r);
     pm_queries_free(q);
     return rc;
-}
+} PM_GUARD_END
 
 // --------------------------------------------------------- 04_filter merge
 // Native form of the reference's consumer (scripts/filter_queries.py:107-206):
@@ -555,7 +555,7 @@ static void merge_index_names(pm_merge* m, size_t first) {
     }
 }
 
-extern "C" int pm_merge_extend(pm_merge_t* m, const pm_queries_t* q) {
+extern "C" int pm_merge_extend(pm_merge_t* m, const pm_queries_t* q) try {
     if (!m || !q) return fail(PM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lk(m->mu);
     const size_t old = m->qname_p.size(), nq = q->headers.size(), total = old + nq;
@@ -596,9 +596,9 @@ extern "C" int pm_merge_extend(pm_merge_t* m, const pm_queries_t* q) {
         for (size_t g = old; g < total; ++g) if (m->canon[g] != g) { m->dup_names = true; break; }
     m->tab_names = m->tab_names || tabs.load();
     return PM_OK;
-}
+} PM_GUARD_END
 
-extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) {
+extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t** out) try {
     if (!q || !out) return fail(PM_EINVAL, "bad argument");
     pm_merge* m = new pm_merge();
     m->keep = keep;
@@ -608,20 +608,20 @@ extern "C" int pm_merge_create(const pm_queries_t* q, uint32_t keep, pm_merge_t*
     if (rc) { delete m; return rc; }
     *out = m;
     return PM_OK;
-}
+} PM_GUARD_END
 
 static int merge_add_impl(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* ix,
                           const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best);
 extern "C" int pm_merge_add(pm_merge_t* m, const char* batch, const pm_index_t* ix,
-                            const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
+                            const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) try {
     return merge_add_impl(m, 0, batch, ix, hits, n_hits, slot, nb_best);
-}
+} PM_GUARD_END
 // the records' query numbers count inside piece `piece` of the query file (pm_merge_extend), or -- piece = -1 -- through
 // the whole file (what pm_merge_export writes: another rank's kept matches)
 extern "C" int pm_merge_add_piece(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* ix,
-                                  const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
+                                  const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) try {
     return merge_add_impl(m, piece, batch, ix, hits, n_hits, slot, nb_best);
-}
+} PM_GUARD_END
 static int merge_add_impl(pm_merge_t* m, int64_t piece, const char* batch, const pm_index_t* ix,
                           const pm_hit_t* hits, uint64_t n_hits, uint32_t slot, int64_t nb_best) {
     if (!m || !batch || !ix || (!hits && n_hits)) return fail(PM_EINVAL, "bad argument");
@@ -753,11 +753,12 @@ static int merge_add_impl(pm_merge_t* m, int64_t piece, const char* batch, const
 // whitespace-separated fields, exactly one '_' in the first; a text without any header and a query that is not
 // in the query file are errors, as they are in the reference (behaviour on odd input captured from the
 // reference's script: tests/golden/filter/edge/).
-extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* text, size_t len) {
+extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* text, size_t len) try {
     if (!m || !batch || (!text && len)) return fail(PM_EINVAL, "bad argument");
     struct Rec { uint32_t target, doc, kmers; };
     std::vector<Rec> recs;
-    std::vector<std::pair<uint32_t, size_t>> blocks;               // (target query, first record) per '*' header
+    struct Block { const char* name; size_t name_len; size_t first; uint32_t target; };
+    std::vector<Block> blocks;                                     // query name and first record per '*' header
     std::unordered_map<std::string, uint32_t> ref_id;
     std::vector<std::string> refs;
     // str.strip() / str.split() whitespace within ASCII: blank, TAB, CR, VT, FF and the separators 0x1c-0x1f
@@ -775,18 +776,26 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
             if (*b == '_') { if (b + 1 >= e || b[1] < '0' || b[1] > '9') return false; continue; }
             if (*b < '0' || *b > '9') return false;
             v = v * 10 + (uint64_t)(*b - '0');
-            if (v > 0xFFFFFFFFull) return false;
+            if (v > 0xFFFFFFFFull) v = 0xFFFFFFFFull;    // Python's int() has no limit: counts are kept as 32 bits, larger ones saturate
         }
         *out = v;
         return true;
     };
     size_t p = 0, lineno = 0;
     bool have_header = false;
+    // lines end at "\n", "\r\n" or a lone "\r": the reference reads the file in text mode with universal newlines
+    // (xopen / open(..., "rt"): scripts/filter_queries.py:46)
+    const bool any_cr = len && memchr(text, '\r', len) != nullptr;
     while (p < len) {
-        const char* nl = (const char*)memchr(text + p, '\n', len - p);
         const char* b = text + p;
+        const char* nl = (const char*)memchr(b, '\n', len - p);
+        size_t eol = 1;
+        if (any_cr) {
+            const char* cr = (const char*)memchr(b, '\r', nl ? (size_t)(nl - b) : len - p);
+            if (cr) { nl = cr; eol = (cr + 1 < text + len && cr[1] == '\n') ? 2 : 1; }
+        }
         const char* e = nl ? nl : text + len;
-        p = (size_t)(e - text) + (nl ? 1 : 0);
+        p = (size_t)(e - text) + (nl ? eol : 0);
         ++lineno;
         while (b < e && is_ws(*b)) ++b;
         while (e > b && is_ws(e[-1])) --e;
@@ -801,11 +810,10 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
                 return fail(PM_EINVAL, "batch %s line %zu: query header without an integer match count", batch, lineno);
             const char* qe = (const char*)memchr(b + 1, ' ', (size_t)(tab - (b + 1)));
             const size_t qn = (size_t)((qe ? qe : tab) - (b + 1));
-            const uint32_t found = m->lookup(b + 1, qn);
-            if (found == pm_merge::kEmpty) return fail(PM_EINVAL, "query '%.*s' of batch %s is not in the query file", (int)qn, b + 1, batch);
             // match lines ahead of the first header join the first query's list: the reference's reader only empties
             // its buffer when it has a query to yield (scripts/filter_queries.py:52-56; pinned by a captured fixture)
-            blocks.push_back({found, have_header ? recs.size() : 0});
+            // (the name is looked up below, under the merge's lock: pm_merge_extend may be growing the table right now)
+            blocks.push_back({b + 1, qn, have_header ? recs.size() : 0, 0u});
             have_header = true;
             continue;
         }
@@ -831,6 +839,11 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
     }
     if (!have_header) return fail(PM_EINVAL, "batch %s: no '*' query header in the match text", batch);
     std::lock_guard<std::mutex> lk(m->mu);
+    for (Block& bl : blocks) {
+        bl.target = m->lookup(bl.name, bl.name_len);
+        if (bl.target == pm_merge::kEmpty)
+            return fail(PM_EINVAL, "query '%.*s' of batch %s is not in the query file", (int)bl.name_len, bl.name, batch);
+    }
     const uint32_t bid = (uint32_t)m->batches.size();
     m->batches.emplace_back();
     MergeBatch& mb = m->batches.back();
@@ -846,8 +859,8 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
         for (size_t i = 0; i < order.size(); ++i) mb.ref_rank[order[i]] = (uint32_t)i;
     }
     for (size_t k = 0; k < blocks.size(); ++k) {
-        const uint32_t target = blocks[k].first;
-        const size_t a = blocks[k].second, b2 = k + 1 < blocks.size() ? blocks[k + 1].second : recs.size();
+        const uint32_t target = blocks[k].target;
+        const size_t a = blocks[k].first, b2 = k + 1 < blocks.size() ? blocks[k + 1].first : recs.size();
         std::vector<MergeItem>& v = m->items[target];
         const size_t before = v.size();
         for (size_t i = a; i < b2; ++i)
@@ -856,13 +869,13 @@ extern "C" int pm_merge_add_text(pm_merge_t* m, const char* batch, const char* t
         if (rc) return rc;
     }
     return PM_OK;
-}
+} PM_GUARD_END
 
 // What is kept so far as hit records {query (numbered through the whole file), doc, score, slot = number of the batch
 // in this merge: pm_merge_batches}, ordered by (slot, query, score desc, doc asc): a rank's share of the 04_filter
 // merge, ready to be gathered (RCCL) and added again on rank 0 -- the best `keep` (+ ties) of the
 // union are among the best `keep` (+ ties) of every part.
-extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n) {
+extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n) try {
     pm_merge* m = const_cast<pm_merge*>(m_);
     if (!m || !out || !n) return fail(PM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lk(m->mu);
@@ -876,10 +889,10 @@ extern "C" int pm_merge_export(const pm_merge_t* m_, pm_hit_t** out, uint64_t* n
     order_hits(buf, total);
     *out = buf; *n = total;
     return PM_OK;
-}
+} PM_GUARD_END
 
 // the batches of the merge in the order of their numbers (the `slot` of pm_merge_export's records), '\n'-separated
-extern "C" int pm_merge_batches(const pm_merge_t* m_, char** names, size_t* len) {
+extern "C" int pm_merge_batches(const pm_merge_t* m_, char** names, size_t* len) try {
     pm_merge* m = const_cast<pm_merge*>(m_);
     if (!m || !names || !len) return fail(PM_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lk(m->mu);
@@ -891,7 +904,7 @@ extern "C" int pm_merge_batches(const pm_merge_t* m_, char** names, size_t* len)
     buf[out.size()] = 0;
     *names = buf; *len = out.size();
     return PM_OK;
-}
+} PM_GUARD_END
 
 // The 04_filter FASTA in blocks of records: exact sizes first (the text is a concatenation of known strings), then every
 // block is formatted straight to its place -- into the caller's buffer, or through a pooled scratch buffer and
@@ -945,8 +958,9 @@ static char* merge_emit_block(const pm_merge* m, const EmitPlan& pl, size_t b, c
     return w;
 }
 
-extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
+extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) try {
     if (!m || !text || !len) return fail(PM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(const_cast<pm_merge_t*>(m)->mu);      // adds and extends wait until the text is out
     EmitPlan pl;
     merge_emit_plan(m, pl);
     const size_t total = (size_t)pl.off.back(), nb = pl.first.size() - 1;
@@ -959,23 +973,24 @@ extern "C" int pm_merge_emit(const pm_merge_t* m, char** text, size_t* len) {
     buf[total] = 0;
     *text = buf; *len = total;
     return PM_OK;
-}
+} PM_GUARD_END
 
 // The same text written to `path` (through "<path>.tmp" + rename: never a partial file that looks
 // complete), the pieces written in parallel at their offsets: the 04_filter FASTA of a million reads
 // is hundreds of MB that need not pass through the caller.
 static int merge_emit_file_impl(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes);
-extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes) {
+extern "C" int pm_merge_emit_file(const pm_merge_t* m, const char* path, uint64_t* bytes) try {
     return merge_emit_file_impl(m, path, 0, bytes);
-}
+} PM_GUARD_END
 // The FASTA of a query file that was searched in chunks (one merge per chunk, in file order): piece 1 = first (creates
 // "<path>.tmp"), 2 = a middle one (appends), 3 = the last (appends, then renames to `path`); 0 = the whole file.
-extern "C" int pm_merge_emit_file_piece(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes) {
+extern "C" int pm_merge_emit_file_piece(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes) try {
     if (piece < 0 || piece > 3) return fail(PM_EINVAL, "piece must be 0 (whole), 1 (first), 2 (middle) or 3 (last)");
     return merge_emit_file_impl(m, path, piece, bytes);
-}
+} PM_GUARD_END
 static int merge_emit_file_impl(const pm_merge_t* m, const char* path, int piece, uint64_t* bytes) {
     if (!m || !path) return fail(PM_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(const_cast<pm_merge_t*>(m)->mu);      // adds and extends wait until the file is written
     EmitPlan pl;
     merge_emit_plan(m, pl);
     const size_t nb = pl.first.size() - 1;

@@ -187,7 +187,8 @@ def split_prepared_fasta(fasta, max_records, piece_bytes=0):
 
 
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
-              want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31):
+              want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31,
+              query_reserve_bytes=0):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
     `batches`).  `queries` is one pm.Queries or a LIST of them (or of Futures of them: a file that is still being parsed):
     the chunks, in file order, of a query file with more reads than fit HBM at once, or of one cut up so that parsing and
@@ -201,7 +202,10 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     chunks = list(queries) if isinstance(queries, (list, tuple)) else [queries]
     nc = len(chunks)
     nb = nb_best_hits
-    budget = budget_bytes if budget_bytes else 0.6 * pm.device_info()["hbm_free"]
+    # HBM for decoded-but-unsearched indexes: 60 % of what is free now, minus what the query chunks in flight will take
+    # (query_reserve_bytes: two chunks are resident at a time -- the one being searched and the one queued behind it;
+    # a chunk's HBM copies are released as soon as its unit is finished, so this does not grow with the file)
+    budget = budget_bytes if budget_bytes else max(0.6 * pm.device_info()["hbm_free"] - query_reserve_bytes, 1.0)
     admit = Admission(budget)
     merge = [None]                                   # the ONE 04_filter merge of the query file, extended piece by piece
     # a chunk may arrive as a Future of its pm.Queries (the file is still being parsed): chunks are made ready in order --
@@ -326,6 +330,11 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             return len(part)
         n_rec = list(workers.map(one, range(len(group))))
         res.free()
+        if nc > 1:
+            # the chunk is searched again only with the next group: its HBM copies (sequences, 8 bytes per k-mer of hashes) go
+            # now, the host side stays for the texts and the merge.  (Waits for nothing: this unit's search has finished and
+            # the unit queued behind it uses another chunk.)
+            qc.release_device()
         if ci == nc - 1:                                 # the group has seen every chunk: its matrices may go
             for pos, ix, held in group:
                 if not resident:
@@ -386,6 +395,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
               "format_s_thread_sum": round(acc["format_s"], 3), "gzip_s_thread_sum": round(acc["gzip_s"], 3),
               "format_and_gzip_in_library": keep_texts is None,
               "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
+              "query_hbm_bytes_at_end": int(sum(chunk(ci).device_bytes()[0] for ci in range(nc))),
               "per_group": group_rows, "merge_order": merge[0].batches() if want_merge else []}
     return report, merge[0]
 
@@ -497,14 +507,17 @@ def main(argv=None):
         # parsed one after the other by a thread of their own (the pieces are views of `fasta`): the stage searches the
         # first pieces while the later ones are still text; term_size is checked against every batch's header
         chunk_list = [parser.submit(pm.Queries, p_, args.kmer_size) for p_ in pieces]
-    del pieces
     budget = args.max_resident_gb * 1e9 if args.max_resident_gb > 0 else None
+    # a query set holds about 9 bytes of HBM per base while it is searched (sequence + 8 bytes of hash per k-mer); two chunks
+    # are resident at a time
+    reserve = 9 * sum(sorted((len(p_) for p_ in pieces), reverse=True)[:2])
+    del pieces
     if args.loaders <= 0:
         from .sysinfo import effective_cpus
         args.loaders = max(4, min(16, effective_cpus() - 4))
     report, merge = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                               want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
-                              max_group=args.max_group, kmer_size=args.kmer_size)
+                              max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve)
     parser.shutdown()
     del fasta
 

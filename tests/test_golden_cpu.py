@@ -1375,3 +1375,17 @@ def test_merge_is_extended_while_other_threads_add(tmp_path):
     for t in ts:
         t.join()
     assert not errs and m.emit() == want
+
+
+def test_exceptions_on_pool_threads_become_error_codes(tmp_path):
+    """tests/native/pool_exceptions.cpp linked against the library's objects: a std::bad_alloc on a worker thread of
+    the library's pool reaches the entry point's PM_GUARD_END (PM_ENOMEM) instead of std::terminate"""
+    import subprocess
+    from phylign_amd import build as B
+    B.build()
+    objs = [os.path.join(B.CSRC, os.path.splitext(s_)[0] + ".o") for s_ in B.SOURCES]
+    exe = str(tmp_path / "pool_exceptions")
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-O1", "-std=c++17", "-x", "hip", os.path.join(ROOT, "tests", "native", "pool_exceptions.cpp"),
+                    "-x", "none"] + objs + ["-lz", "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"pool exceptions ok" in r.stdout, (r.returncode, r.stderr.decode()[-500:])

@@ -247,6 +247,7 @@ def test_match_stage_searches_a_large_query_file_in_chunks(pm, oracle, tmp_path,
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
     assert r.stderr.count(b'"query_chunks": 3') == ranks          # every rank reports its three chunks
+    assert r.stderr.count(b'"query_hbm_bytes_at_end": 0') == ranks   # ... and none of them is still resident
     assert not list((tmp_path / "03_match").glob("*.tmp"))
 
 
@@ -487,3 +488,40 @@ def test_match_stage_plain_invocation_with_eight_ranks(pm, oracle, tmp_path):
     reports = [json.loads(ln) for ln in r.stderr.decode().splitlines() if ln.startswith("{") and '"world"' in ln]
     assert sorted(rep["rank"] for rep in reports) == list(range(8)) and all(rep["world"] == 8 for rep in reports)
     assert sorted(rep["batches"] for rep in reports) == [0, 0, 0, 1, 1, 1, 1, 1]
+
+
+def test_query_chunks_do_not_accumulate_in_hbm(pm, oracle, tmp_path):
+    """a query file searched chunk after chunk holds at most two chunks' device state at a time: every chunk's HBM copies
+    (sequences, 8 bytes of hash per k-mer) are released once its unit is finished, so the free HBM after the stage does
+    not depend on the number of chunks -- and a released set is simply uploaded again by its next search"""
+    from phylign_amd import match_stage as MS
+    from phylign_amd import workload as W
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    batches = sorted(names)
+    src = MS.ResidentSource({b: pm.Index.load_mem(indexes[b]) for b in batches})
+    big, _ = W.make_queries(60000, 150, seed=9)                       # 60 k reads: ~66 MB of device state in one piece
+    free_after = {}
+    for nchunks in (1, 6):
+        pieces = MS.split_prepared_fasta(big, 60000 // nchunks)
+        assert len(pieces) == nchunks
+        chunks = [pm.Queries(bytes(p_)) for p_ in pieces]
+        rep, _ = MS.run_stage(pm, batches, list(range(len(batches))), src, chunks if nchunks > 1 else chunks[0], "big",
+                              str(tmp_path / f"03_{nchunks}"), 0.7, 3)
+        per_chunk = [c.device_bytes() for c in chunks]
+        if nchunks > 1:
+            assert rep["query_hbm_bytes_at_end"] == 0 and all(res == 0 and need > 1 << 20 for res, need in per_chunk)
+        else:
+            assert per_chunk[0][0] == per_chunk[0][1] > 60 << 20
+            chunks[0].release_device()
+            assert chunks[0].device_bytes()[0] == 0
+        free_after[nchunks] = pm.device_info()["hbm_free"]
+        # a released set is searched again like a fresh one
+        a = pm.search([src.indexes[batches[0]]], chunks[-1], 0.7).hits()
+        chunks[-1].release_device()
+        b = pm.search([src.indexes[batches[0]]], chunks[-1], 0.7).hits()
+        assert np.array_equal(a, b)
+        for c in chunks:
+            c.free()
+    assert abs(free_after[1] - free_after[6]) < 32 << 20, free_after
+    for b in batches:                                                 # the pieces of a batch's file are the one-piece file
+        assert gzip.open(tmp_path / "03_1" / f"{b}____big.gz", "rb").read() == gzip.open(tmp_path / "03_6" / f"{b}____big.gz", "rb").read()

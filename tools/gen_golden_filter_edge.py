@@ -28,6 +28,10 @@ CASES = {
     "ties_past_keep": "*r4\t6\na_R6\t30\nb_R5\t30\nc_R4\t29\nd_R3\t29\ne_R2\t29\nf_R1\t28\n",
     "empty_reference_name": "*r1\t1\nzz_\t30\n",
     "empty_random_id": "*r1\t1\n_SAMA\t30\n",
+    # text mode = universal newlines: a lone CR ends a line too
+    "bare_cr_line_ends": "*r1 descr\t2\rzz_SAMA\t30\rzz_SAMB\t29\r*r2\t1\ryy_SAMC\t28\r",
+    "mixed_line_ends": "*r1 descr\t2\r\nzz_SAMA\t30\rzz_SAMB\t29\n\r*r2\t1\n\nyy_SAMC\t28",
+    "count_above_32_bits": "*r1\t1\nzz_SAMA\t4294967296\n",
 }
 shim = tempfile.mkdtemp()
 with open(os.path.join(shim, "xopen.py"), "w") as f:

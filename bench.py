@@ -48,23 +48,7 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 from phylign_amd.sysinfo import effective_cpus  # noqa: E402
 
 
-def host_memory_gb():
-    """GB of host RAM this process may still take: MemAvailable, capped by what the cgroup leaves"""
-    avail = None
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable:"):
-                avail = int(line.split()[1]) * 1024
-    except Exception:
-        pass
-    try:
-        lim = open("/sys/fs/cgroup/memory.max").read().strip()
-        if lim != "max":
-            cur = int(open("/sys/fs/cgroup/memory.current").read())
-            avail = min(avail, int(lim) - cur) if avail is not None else int(lim) - cur
-    except Exception:
-        pass
-    return (avail or 8 << 30) / 1e9
+from phylign_amd.sysinfo import available_ram_gb as host_memory_gb  # noqa: E402
 
 
 def kernel_blob_hash():

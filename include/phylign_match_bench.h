@@ -46,6 +46,10 @@ void pm_bench_hashes_free(pm_bench_hashes_t* h);
  * own species (many documents near the threshold, long hit lists). */
 int pm_bench_index_plant_cluster(pm_index_t* idx, const pm_bench_hashes_t* h, uint32_t q_first, uint32_t q_step, uint64_t seed);
 
+/* writes a resident classic index back as a .cobs_classic file (for the cold / cached / resident timings of the stage
+ * on 661k-shaped files: tools/e2e_cold_warm.py) */
+int pm_bench_index_save(const pm_index_t* idx, const char* path);
+
 /* Times a pure random-row gather over this index with k_scan's access pattern (n_groups
  * row-cooperating lane groups x lookups_per_group rows each, no counting); *ms = hipEvent time,
  * *bytes = rows fetched x row_bytes: the memory-system ceiling the scan kernel is compared with.

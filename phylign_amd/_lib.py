@@ -62,6 +62,7 @@ SYMBOLS = [
     ("pm_index_load_file", C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(_P)]),
     ("pm_index_load_fd", C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(_P)]),
     ("pm_index_load_mem", C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
+    ("pm_index_load_fd_tee", C.c_int, [C.c_int, C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(_P)]),
     ("pm_index_load_header_mem", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     ("pm_index_create", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.POINTER(_P)]),
     ("pm_index_matrix_device", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
@@ -158,6 +159,13 @@ def init(device=0):
     _inited_device = device
 
 
+def shutdown():
+    """releases the library's streams and pooled buffers (init() may be called again)"""
+    global _inited_device
+    load().pm_shutdown()
+    _inited_device = None
+
+
 def bound_device():
     """GPU ordinal given to init() (None before)"""
     return _inited_device
@@ -191,10 +199,17 @@ class Index:
         return cls(h)
 
     @classmethod
-    def load_fd(cls, fd, size_hint=0, layout=PM_LAYOUT_AUTO):
+    def load_fd(cls, fd, size_hint=0, layout=PM_LAYOUT_AUTO, tee_path=None):
+        """tee_path: also keep the stream as that file (decode-once cache); the index's `cached` says whether it exists"""
         h = _P()
-        _chk(load().pm_index_load_fd(fd, size_hint, layout, C.byref(h)))
-        return cls(h)
+        if tee_path is None:
+            _chk(load().pm_index_load_fd(fd, size_hint, layout, C.byref(h)))
+            return cls(h)
+        cached = C.c_int(0)
+        _chk(load().pm_index_load_fd_tee(fd, size_hint, layout, os.fsencode(tee_path), C.byref(cached), C.byref(h)))
+        ix = cls(h)
+        ix.cached = bool(cached.value)
+        return ix
 
     @classmethod
     def load_mem(cls, buf, layout=PM_LAYOUT_AUTO):

@@ -20,6 +20,7 @@ SYMBOLS = [
     ("pm_bench_hashes_create", C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(_P)]),
     ("pm_bench_hashes_free", None, [_P]),
     ("pm_bench_index_plant_cluster", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64]),
+    ("pm_bench_index_save", C.c_int, [_P, C.c_char_p]),
     ("pm_bench_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 ]
 _aids = None
@@ -99,3 +100,8 @@ def probe_gather(index, n_groups, lookups_per_group, mode=None, flavor=None, unr
     ms, nb = C.c_double(), C.c_uint64()
     _chk(load().pm_bench_probe_gather(index._h, n_groups, lookups_per_group, mode, flavor, unroll, C.byref(ms), C.byref(nb)))
     return ms.value, nb.value
+
+
+def index_save(index, path):
+    """writes a resident classic index back as a .cobs_classic file"""
+    _chk(load().pm_bench_index_save(index._h, os.fsencode(path)))

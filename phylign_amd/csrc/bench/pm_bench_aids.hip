@@ -4,6 +4,7 @@
 // ceiling for k_scan's access pattern.  None of this is on the matching path; it reaches the product
 // library only through its C ABI (pm_index_create / pm_index_matrix_device / pm_hash_terms ...).
 #include <hip/hip_runtime.h>
+#include <errno.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -452,5 +453,39 @@ extern "C" int pm_bench_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
     if (e != hipSuccess) return bfail(PM_EHIP, "probe: %s", hipGetErrorString(e));
     *ms = f; *bytes = n_groups * lookups_per_group * info.row_bytes;
+    return PM_OK;
+}
+
+// A resident classic index written back as a .cobs_classic file (header in the first of the two field orders the
+// product's reader accepts): lets a measurement put 661k-SHAPED index files -- and their .xz -- on
+// disk for the cold / cached / resident timings of the stage (tools/e2e_cold_warm.py).
+extern "C" int pm_bench_index_save(const pm_index_t* ix, const char* path) {
+    if (!ix || !path) return bfail(PM_EINVAL, "bad argument");
+    pm_index_info_t in;
+    BPM(pm_index_info(ix, &in));
+    if (!in.has_matrix || in.n_parts) return bfail(PM_EINVAL, "only a resident classic index can be saved");
+    FILE* f = fopen(path, "wb");
+    if (!f) return bfail(PM_EIO, "cannot create '%s': %s", path, strerror(errno));
+    bool ok = fwrite("COBS:CLASSIC_INDEX", 1, 18, f) == 18;
+    const uint32_t ver = 1; const uint8_t canon = (uint8_t)in.canonicalize; const uint64_t nh = in.num_hashes;
+    ok = ok && fwrite(&ver, 4, 1, f) == 1 && fwrite(&in.term_size, 4, 1, f) == 1 && fwrite(&canon, 1, 1, f) == 1 &&
+         fwrite(&in.n_docs, 4, 1, f) == 1 && fwrite(&in.signature_size, 8, 1, f) == 1 && fwrite(&nh, 8, 1, f) == 1;
+    for (uint32_t d = 0; d < in.n_docs && ok; ++d) {
+        size_t l = 0;
+        const char* nm = pm_index_doc_name(ix, d, &l);
+        ok = nm && fwrite(nm, 1, l, f) == l && fputc('\n', f) != EOF;
+    }
+    ok = ok && fwrite("CLASSIC_INDEX", 1, 13, f) == 13;
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / in.row_bytes);
+    std::vector<uint8_t> buf((size_t)(std::min<uint64_t>(chunk, in.signature_size) * in.row_bytes));
+    int rc = PM_OK;
+    for (uint64_t r = 0; r < in.signature_size && ok && !rc; r += chunk) {
+        const uint64_t n = std::min<uint64_t>(chunk, in.signature_size - r);
+        rc = pm_index_read_rows(ix, r, n, buf.data());
+        if (!rc) ok = fwrite(buf.data(), 1, (size_t)(n * in.row_bytes), f) == (size_t)(n * in.row_bytes);
+    }
+    if (fclose(f) != 0) ok = false;
+    if (rc) { (void)remove(path); return bfail(rc, "%s", pm_last_error()); }
+    if (!ok) { (void)remove(path); return bfail(PM_EIO, "writing '%s' failed", path); }
     return PM_OK;
 }

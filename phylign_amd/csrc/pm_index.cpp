@@ -136,6 +136,15 @@ struct Reader {
     int fd = -1;
     const uint8_t* mem = nullptr; size_t mem_len = 0, mem_pos = 0;
     std::vector<uint8_t> pending; size_t pend_pos = 0;
+    // decode-once cache: everything read from `fd` is also written here (pm_index_load_fd_tee)
+    int tee_fd = -1; int tee_errno = 0; uint64_t tee_bytes = 0;
+    void tee(const uint8_t* p, size_t n) {
+        while (n && tee_fd >= 0 && !tee_errno) {
+            ssize_t w = ::write(tee_fd, p, n);
+            if (w < 0) { if (errno == EINTR) continue; tee_errno = errno; return; }
+            p += w; n -= (size_t)w; tee_bytes += (uint64_t)w;
+        }
+    }
     // returns bytes read (< n only at EOF), -1 on error
     ssize_t read_full(uint8_t* dst, size_t n) {
         size_t got = 0;
@@ -152,6 +161,7 @@ struct Reader {
             ssize_t r = ::read(fd, dst + got, n - got);
             if (r < 0) { if (errno == EINTR) continue; return -1; }
             if (r == 0) break;
+            if (tee_fd >= 0) tee(dst + got, (size_t)r);
             got += (size_t)r;
         }
         return (ssize_t)got;
@@ -478,6 +488,32 @@ extern "C" int pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index
     if (!out || fd < 0) return fail(PM_EINVAL, "bad argument");
     Reader rd; rd.fd = fd;
     return load_from_reader(rd, size_hint, layout, false, out);
+} PM_GUARD_END
+// The decode-once cache of a compressed index (the reference's `mem-disk` mode with
+// keep_cobs_indexes, Snakefile:364-387): while the stream (`xzcat` pipe) is loaded into HBM every byte read is also
+// written to "<tee_path>.tmp", which becomes `tee_path` once the whole index has arrived -- a later run finds the plain
+// file and takes the parallel pread path instead of decoding again.  A failed load leaves no file behind; a failed
+// WRITE (disk full) does not fail the load: the index is resident, only the cache file is dropped (*cached = 0).
+extern "C" int pm_index_load_fd_tee(int fd, uint64_t size_hint, int layout, const char* tee_path, int* cached, pm_index_t** out) try {
+    NEED_DEV();
+    if (!out || fd < 0 || !tee_path) return fail(PM_EINVAL, "bad argument");
+    if (cached) *cached = 0;
+    const std::string tmp = std::string(tee_path) + ".tmp";
+    Reader rd; rd.fd = fd;
+    rd.tee_fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (rd.tee_fd < 0) rd.tee_errno = errno;                  // no cache file: the load itself goes on
+    int rc = load_from_reader(rd, size_hint, layout, false, out);
+    bool ok = rc == PM_OK && rd.tee_fd >= 0 && !rd.tee_errno;
+    if (ok) {
+        // the index ends where its matrix ends: the cache file must hold exactly header + matrix bytes
+        pm_index_info_t in = (*out)->info;
+        ok = in.n_parts == 0 && rd.tee_bytes >= in.signature_size * in.row_bytes;
+    }
+    if (rd.tee_fd >= 0) { if (close(rd.tee_fd) != 0) ok = false; }
+    if (ok && rename(tmp.c_str(), tee_path) != 0) ok = false;
+    if (!ok) (void)unlink(tmp.c_str());
+    if (cached) *cached = ok ? 1 : 0;
+    return rc;
 } PM_GUARD_END
 extern "C" int pm_index_load_file(const char* path, uint64_t size_hint, int layout, pm_index_t** out) try {
     NEED_DEV();

@@ -91,13 +91,14 @@ class Admission:
             self.cv.notify_all()
 
 
-def open_index_stream(cobs_dir, batch):
+def open_index_stream(cobs_dir, batch, cache_dir=None):
     """(file object, process or None): the plain index if it was decompressed
-    already (Snakefile:364-387), else an xzcat pipe (run_cobs_streaming.sh:27)"""
-    plain = os.path.join(cobs_dir, f"{batch}.cobs_classic")
-    if os.path.exists(plain):
-        return open(plain, "rb"), None
-    xz = plain + ".xz"
+    already (Snakefile:364-387; in <cache_dir> or next to the .xz), else an xzcat pipe (run_cobs_streaming.sh:27)"""
+    for d in ([cache_dir] if cache_dir else []) + [cobs_dir]:
+        plain = os.path.join(d, f"{batch}.cobs_classic")
+        if os.path.exists(plain):
+            return open(plain, "rb"), None
+    xz = os.path.join(cobs_dir, f"{batch}.cobs_classic.xz")
     if not os.path.exists(xz):
         raise FileNotFoundError(xz)
     p = subprocess.Popen(["xzcat", "--no-sparse", "--ignore-check", xz], stdout=subprocess.PIPE)
@@ -105,24 +106,52 @@ def open_index_stream(cobs_dir, batch):
 
 
 class FileSource:
-    """indexes read from <cobs-dir>/<batch>.cobs_classic[.xz] (what the reference's rules read)"""
+    """indexes read from <cobs-dir>/<batch>.cobs_classic[.xz] (what the reference's rules read).
 
-    def __init__(self, pm, cobs_dir, sizes):
-        self.pm, self.cobs_dir, self.sizes = pm, cobs_dir, sizes
+    cache_dir: the decode-once cache (the reference's index_load_mode mem-disk + keep_cobs_indexes, config.yaml:91-104,
+    rule decompress_cobs Snakefile:364-387): a batch that had to be decoded from .xz leaves
+    <cache_dir>/<batch>.cobs_classic behind (written while it streams into HBM, tmp + rename), and the next stage run
+    reads that file with the parallel pread loader instead of decoding again."""
+
+    def __init__(self, pm, cobs_dir, sizes, cache_dir=None, host_ram=None, host_mb=None):
+        self.pm, self.cobs_dir, self.sizes, self.cache_dir = pm, cobs_dir, sizes, cache_dir
+        # host-RAM admission of the xz decoders (sizing.HostRam / sizing.stage_plan: the reference's max_ram_gb)
+        self.host_ram, self.host_mb = host_ram, host_mb or {}
+        self.counts = {"xz_decoded": 0, "plain_files": 0, "cache_files_written": 0}
+        self._mu = threading.Lock()
+        if cache_dir:
+            os.makedirs(cache_dir, exist_ok=True)
 
     def need(self, batch):
         # what the loader may allocate at most: the line-aligned layout never needs more than twice
         # the file's bytes (a 65-byte row becomes 128), plus the two 32 MiB staging chunks
         return 2.0 * float(self.sizes.get(batch, 0)) + (128 << 20)
 
+    def is_compressed(self, batch):
+        return not any(os.path.exists(os.path.join(d, f"{batch}.cobs_classic")) for d in ([self.cache_dir] if self.cache_dir else []) + [self.cobs_dir])
+
     def load(self, batch):
-        fobj, proc = open_index_stream(self.cobs_dir, batch)
+        # a decoder is admitted to the host-RAM budget before it starts (a plain file needs only the pooled staging)
+        mb = self.host_mb.get(batch, 0) if (self.host_ram is not None and self.is_compressed(batch)) else 0
+        if mb:
+            self.host_ram.acquire(mb)
         try:
-            ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0))
+            fobj, proc = open_index_stream(self.cobs_dir, batch, self.cache_dir)
+            tee = os.path.join(self.cache_dir, f"{batch}.cobs_classic") if (self.cache_dir and proc is not None) else None
+            try:
+                ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0), tee_path=tee)
+            finally:
+                fobj.close()
+                if proc is not None and proc.wait() != 0:
+                    if tee and os.path.exists(tee):
+                        os.unlink(tee)                      # whatever the decoder choked on is not a cache entry
+                    raise RuntimeError(f"xzcat failed on batch {batch}")
         finally:
-            fobj.close()
-            if proc is not None and proc.wait() != 0:
-                raise RuntimeError(f"xzcat failed on batch {batch}")
+            if mb:
+                self.host_ram.release(mb)
+        with self._mu:
+            self.counts["xz_decoded" if proc is not None else "plain_files"] += 1
+            self.counts["cache_files_written"] += int(bool(tee and getattr(ix, "cached", False)))
         return ix
 
 
@@ -396,7 +425,8 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
               "format_and_gzip_in_library": keep_texts is None,
               "merge_s_thread_sum": round(acc["merge_s"], 3), "stage_wall_s": round(time.perf_counter() - t_start, 3),
               "query_hbm_bytes_at_end": int(sum(chunk(ci).device_bytes()[0] for ci in range(nc))),
-              "per_group": group_rows, "merge_order": merge[0].batches() if want_merge else []}
+              "per_group": group_rows, "merge_order": merge[0].batches() if want_merge else [],
+              "index_source": dict(getattr(source, "counts", {}), resident=len(mine) if resident else 0)}
     return report, merge[0]
 
 
@@ -422,8 +452,21 @@ def main(argv=None):
     ap.add_argument("--nb-best-hits", type=int, default=100)         # config.yaml:23
     ap.add_argument("--filter-out", default=None)
     ap.add_argument("--loaders", type=int, default=0,
-                    help="concurrent xz decoders per rank (0 = the CPUs the job may use minus 4, at least 4, at most 16: one "
-                         "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for)")
+                    help="concurrent xz decoders per rank (0 = the CPUs the job may use minus 4, at least 4, at most 16 -- one "
+                         "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for -- and no "
+                         "more than fit --max-ram-gb at the decoder size the sizes table states: sizing.stage_plan)")
+    ap.add_argument("--max-ram-gb", type=float, default=0.0,
+                    help="config.yaml max_ram_gb: host RAM the stage's xz decoders may hold together (the sizes table's third "
+                         "column per decoder, Snakefile:64-69; the index itself is in HBM).  0 = 80 %% of the RAM available now")
+    ap.add_argument("--cache-dir", default=None,
+                    help="decode-once cache: a batch decoded from .xz is also written to <dir>/<batch>.cobs_classic (tmp + rename) "
+                         "while it streams into HBM; later runs load that file (parallel pread, tens of GB/s) instead of "
+                         "decoding again.  The reference's index_load_mode mem-disk with keep_cobs_indexes (config.yaml:91-104)")
+    ap.add_argument("--index-load-mode", default="mem-stream", choices=["mem-stream", "mem-disk", "mmap-disk"],
+                    help="config.yaml:91-104.  mem-stream: decode straight into HBM (with --cache-dir the decoded bytes are kept "
+                         "too); mem-disk: the same plus the cache in --decompression-dir (required); mmap-disk has no "
+                         "meaning for a matrix that lives in HBM and is taken as mem-disk")
+    ap.add_argument("--decompression-dir", default=None, help="config.yaml decompression_dir (mem-disk): where decoded indexes are kept")
     ap.add_argument("--max-resident-gb", type=float, default=0.0, help="HBM budget for decoded-but-unsearched indexes (0 = 60%% of free)")
     ap.add_argument("--query-piece-mb", type=int, default=48,
                     help="a prepared query file of more than twice this many MB is parsed and searched in pieces of about this "
@@ -482,7 +525,12 @@ def main(argv=None):
             ap.error("--batches and --cobs-dir are required (unless --synthetic)")
         batches = read_batches(args.batches)
         sizes = read_sizes(args.sizes)
-        source = FileSource(pm, args.cobs_dir, sizes)
+        cache_dir = args.cache_dir
+        if args.index_load_mode != "mem-stream":
+            cache_dir = cache_dir or args.decompression_dir
+            if not cache_dir:
+                ap.error("--index-load-mode mem-disk needs --decompression-dir (or --cache-dir)")
+        source = FileSource(pm, args.cobs_dir, sizes, cache_dir=cache_dir)
     parts = W.assign_named(batches, sizes, world)
     mine = parts[rank]
     qfile = os.path.basename(args.queries)
@@ -512,9 +560,17 @@ def main(argv=None):
     # are resident at a time
     reserve = 9 * sum(sorted((len(p_) for p_ in pieces), reverse=True)[:2])
     del pieces
-    if args.loaders <= 0:
-        from .sysinfo import effective_cpus
-        args.loaders = max(4, min(16, effective_cpus() - 4))
+    # loaders and their host RAM by the reference's sizing rules (Snakefile:60-121 -> sizing.py): the decoder size of every
+    # batch of this rank from the sizes table, the budget from --max-ram-gb
+    from . import sizing
+    from .sysinfo import effective_cpus, available_ram_gb
+    max_ram_gb = args.max_ram_gb if args.max_ram_gb > 0 else 0.8 * available_ram_gb()
+    args.loaders, budget_mb, host_mb = sizing.stage_plan([batches[p_] for p_ in mine], args.sizes, effective_cpus(), max_ram_gb,
+                                                        args.loaders)
+    host_ram = None
+    if isinstance(source, FileSource):
+        host_ram = source.host_ram = sizing.HostRam(budget_mb)
+        source.host_mb = host_mb
     report, merge = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                               want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
                               max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve)
@@ -554,6 +610,9 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    report["host_ram_plan"] = {"loaders": args.loaders, "budget_mb": budget_mb,
+                               "decoder_mb_max": max(host_mb.values()) if host_mb else 0,
+                               "decoders_peak_mb": host_ram.peak if host_ram is not None else 0}
     report.update({"rank": rank, "world": world, "e2e_s": round(time.perf_counter() - t_start, 3)})
     sys.stderr.write(json.dumps(report) + "\n")          # one write: the lines of several ranks must not interleave
     sys.stderr.flush()
@@ -564,7 +623,7 @@ def names_index(pm, source, batch):
     if isinstance(source, SynthSource):
         s = source.by_name[batch]
         return pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, source.seed, header_only=True)
-    fobj, proc = open_index_stream(source.cobs_dir, batch)
+    fobj, proc = open_index_stream(source.cobs_dir, batch, getattr(source, "cache_dir", None))
     try:
         head = bytearray()
         while True:                                                   # the header ends with the closing magic: read until it parses

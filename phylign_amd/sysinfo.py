@@ -23,3 +23,22 @@ def effective_cpus():
         except Exception:
             pass
     return max(1, n)
+
+
+def available_ram_gb():
+    """GB of host RAM this process may still take: MemAvailable, capped by what the cgroup leaves"""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, int(lim) - cur) if avail is not None else int(lim) - cur
+    except Exception:
+        pass
+    return (avail or 8 << 30) / 1e9

@@ -286,3 +286,44 @@ def test_bench_and_stage_self_launch_before_touching_the_gpu():
     r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--gpus", "2", "--synthetic", "small", "--queries", os.devnull,
                         "--out-dir", os.devnull], capture_output=True, timeout=300, cwd="/", env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode != 0 and b"[launch] rank" in r.stderr
+
+
+def test_stage_plan_sizes_loaders_by_the_reference_rules(tmp_path):
+    """sizing.stage_plan / HostRam: the number of xz decoders of a stage run and the host RAM they may hold together come
+    from the reference's sizing helpers (Snakefile:60-121): decoder RAM per batch from the sizes table's third column,
+    the budget from max_ram_gb -- a loader is admitted while the running ones' decoders plus its own fit"""
+    import threading
+    import time
+    from phylign_amd import sizing
+    sz = tmp_path / "sizes.txt"
+    sz.write_text("cobs/a__01.cobs_classic.xz  1000000000  1610678320\n"
+                  "cobs/b__01.cobs_classic.xz  5000000000  1610678320\n"
+                  "cobs/c__01.cobs_classic.xz  200000000  68157440\n")
+    assert sizing.xz_ram_mb("a__01", str(sz)) == 1537 and sizing.loader_host_mb("c__01", str(sz)) == 66 + 64
+    assert sizing.loader_host_mb("unknown__01", str(sz)) == 1536 + 64
+    n, budget, need = sizing.stage_plan(["a__01", "b__01", "c__01"], str(sz), cpus=16, max_ram_gb=12)
+    assert budget == 12 * 1024 and need == {"a__01": 1601, "b__01": 1601, "c__01": 130}
+    assert n == 7                                         # 12 GiB hold seven 1.5-GiB decoders; the CPUs would allow 12
+    assert sizing.stage_plan(["a__01"], str(sz), cpus=16, max_ram_gb=64)[0] == 12
+    assert sizing.stage_plan(["a__01"], str(sz), cpus=6, max_ram_gb=64)[0] == 4
+    assert sizing.stage_plan(["a__01"], str(sz), cpus=64, max_ram_gb=1)[0] == 1
+    assert sizing.stage_plan(["a__01"], str(sz), cpus=64, max_ram_gb=1, loaders=5)[0] == 5      # an explicit --loaders stands
+    # what the reference reserves per streaming job = index MB + decoder MB (Snakefile:72-82); ours is the decoder's share
+    assert sizing.batch_ram_mb("b__01", str(sz)) == 4769 + 1537
+    ram = sizing.HostRam(4000)
+    running, peak, lock = [0], [0], threading.Lock()
+
+    def loader(mb):
+        ram.acquire(mb)
+        with lock:
+            running[0] += mb
+            peak[0] = max(peak[0], running[0])
+        time.sleep(0.01)
+        with lock:
+            running[0] -= mb
+        ram.release(mb)
+    ts = [threading.Thread(target=loader, args=(mb,)) for mb in [1601] * 6 + [130] * 5 + [5000]]
+    [t.start() for t in ts]
+    [t.join(timeout=30) for t in ts]
+    assert not any(t.is_alive() for t in ts) and ram.held == 0
+    assert peak[0] <= 5000 and ram.peak == peak[0]        # (the 5000-MB loader ran alone)

@@ -525,3 +525,48 @@ def test_query_chunks_do_not_accumulate_in_hbm(pm, oracle, tmp_path):
     assert abs(free_after[1] - free_after[6]) < 32 << 20, free_after
     for b in batches:                                                 # the pieces of a batch's file are the one-piece file
         assert gzip.open(tmp_path / "03_1" / f"{b}____big.gz", "rb").read() == gzip.open(tmp_path / "03_6" / f"{b}____big.gz", "rb").read()
+
+
+def test_match_stage_decode_once_cache(pm, oracle, tmp_path):
+    """--cache-dir: the first run decodes every .xz into HBM and leaves <cache>/<batch>.cobs_classic behind (the bytes of
+    the decoded stream, no .tmp); the second run finds them and decodes nothing; both runs write the same files.  The
+    loader plan comes from the sizes table (sizing.stage_plan); mem-disk is the same thing under the reference's name"""
+    import json
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cache = tmp_path / "cache"
+    base = [sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+            "--cobs-dir", str(tmp_path / "cobs"), "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"),
+            "--nb-best-hits", "3", "--max-ram-gb", "4"]
+    reports = []
+    for run, extra in enumerate((["--cache-dir", str(cache)], ["--cache-dir", str(cache)],
+                                 ["--index-load-mode", "mem-disk", "--decompression-dir", str(cache)])):
+        out = tmp_path / f"03_match_{run}"
+        r = subprocess.run(base + ["--out-dir", str(out), "--filter-out", str(tmp_path / f"04_{run}" / "Q.fa")] + extra,
+                           capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        reports.append(json.loads([ln for ln in r.stderr.decode().splitlines() if ln.startswith("{")][-1]))
+    assert reports[0]["index_source"] == {"xz_decoded": 5, "plain_files": 0, "cache_files_written": 5, "resident": 0}
+    assert reports[1]["index_source"] == {"xz_decoded": 0, "plain_files": 5, "cache_files_written": 0, "resident": 0}
+    assert reports[2]["index_source"] == reports[1]["index_source"]
+    plan = reports[0]["host_ram_plan"]
+    assert plan["budget_mb"] == 4096 and plan["decoder_mb_max"] == 1537 + 64 and plan["loaders"] == 2
+    assert 0 < plan["decoders_peak_mb"] <= 4096 and reports[1]["host_ram_plan"]["decoders_peak_mb"] == 0
+    assert sorted(f.name for f in cache.iterdir()) == sorted(f"{b}.cobs_classic" for b in names)
+    for b in names:
+        assert (cache / f"{b}.cobs_classic").read_bytes() == bytes(indexes[b])
+        for run in (1, 2):
+            assert (tmp_path / f"03_match_{run}" / f"{b}____Q.gz").read_bytes() == (tmp_path / "03_match_0" / f"{b}____Q.gz").read_bytes()
+    (tmp_path / "03_match").mkdir()
+    for f in (tmp_path / "03_match_1").iterdir():
+        (tmp_path / "03_match" / f.name).write_bytes(f.read_bytes())
+    (tmp_path / "04_filter").mkdir()
+    (tmp_path / "04_filter" / "Q.fa").write_bytes((tmp_path / "04_1" / "Q.fa").read_bytes())
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    # a truncated stream leaves no cache entry
+    broken = sorted(names)[1]
+    (cache / f"{broken}.cobs_classic").unlink()
+    (tmp_path / "cobs" / f"{broken}.cobs_classic.xz").write_bytes(lzma.compress(bytes(indexes[broken][: len(indexes[broken]) // 2]), preset=1))
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_match_x"), "--cache-dir", str(cache)], capture_output=True, env=env)
+    assert r.returncode != 0
+    assert not (cache / f"{broken}.cobs_classic").exists() and not list(cache.glob("*.tmp"))

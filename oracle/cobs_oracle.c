@@ -86,8 +86,15 @@ int orc_canonicalize(const char* kmer, size_t k, char* out) {
 /* Minimum score kept: ceil(threshold * num_terms) in IEEE double (upstream
  * cobs/query/classic_search.cpp, counts_to_result).  `-t 0.7` comes from
  * config.yaml:20 through Snakefile:410 / :451. */
+/* The two rules no file of the reference pins (SURVEY.md 8c "unresolvable here") are switchable, like the product's
+ * pm_set_option("cobs_threshold_rule" / "cobs_tie_order"): tools/pin_against_cobs.sh decides them against a real
+ * cobs 0.2.1.  threshold_rule 0 = ceil (default), 1 = floor, 2 = round half up; tie_desc 1 = equal scores by
+ * descending document index (default 0: ascending). */
+static int g_threshold_rule = 0, g_tie_desc = 0;
+void orc_set_rules(int threshold_rule, int tie_desc) { g_threshold_rule = threshold_rule; g_tie_desc = tie_desc; }
 uint32_t orc_threshold(double threshold, uint64_t num_terms) {
-    double t = ceil(threshold * (double)num_terms);
+    const double x = threshold * (double)num_terms;
+    double t = g_threshold_rule == 1 ? floor(x) : (g_threshold_rule == 2 ? floor(x + 0.5) : ceil(x));
     if (t < 0) t = 0;
     if (t > 4294967295.0) t = 4294967295.0;
     return (uint32_t)t;
@@ -217,6 +224,7 @@ int orc_scores(const uint8_t* matrix, uint64_t stride, const orc_header_t* h,
 static int cmp_hit(const void* a, const void* b) {
     const orc_hit_t* x = (const orc_hit_t*)a; const orc_hit_t* y = (const orc_hit_t*)b;
     if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    if (g_tie_desc) return x->doc > y->doc ? -1 : (x->doc < y->doc);
     return x->doc < y->doc ? -1 : (x->doc > y->doc);
 }
 size_t orc_select(const uint32_t* scores, uint32_t n_docs, uint64_t num_terms,

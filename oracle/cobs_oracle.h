@@ -42,6 +42,7 @@ typedef struct { uint32_t doc; uint32_t score; } orc_hit_t;
 uint64_t orc_xxh64(const void* data, size_t len, uint64_t seed);
 int  orc_canonicalize(const char* kmer, size_t k, char* out);
 uint32_t orc_threshold(double threshold, uint64_t num_terms);
+void orc_set_rules(int threshold_rule, int tie_desc);   /* the two unpinned rules: see cobs_oracle.c */
 
 int  orc_header_parse(const uint8_t* buf, size_t len, orc_header_t* h);
 /* returns malloc'd buffer holding a complete classic index; matrix zeroed */

@@ -96,6 +96,13 @@ def threshold(t: float, num_terms: int) -> int:
     return lib().orc_threshold(t, num_terms)
 
 
+def set_rules(threshold_rule=0, tie_order=0):
+    """the two rules of `cobs query` no reference file pins: threshold_rule 0 = ceil(t * k-mers) (default), 1 = floor,
+    2 = round half up; tie_order 0 = equal scores by ascending document index (default), 1 = descending.  The product's
+    pm_set_option("cobs_threshold_rule" / "cobs_tie_order") take the same values."""
+    lib().orc_set_rules(int(threshold_rule), int(tie_order))
+
+
 def header_parse(buf) -> Header:
     import numpy as np
     a = np.frombuffer(buf, dtype=np.uint8)

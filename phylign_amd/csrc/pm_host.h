@@ -144,7 +144,7 @@ struct pm_queries {
     QDesc* d_qd = nullptr;
     uint32_t* d_blkq = nullptr;
     uint32_t* d_qmap = nullptr;
-    uint32_t* d_thr = nullptr; double thr_for = -1.0;      // per-query minimum score, cached per threshold
+    uint32_t* d_thr = nullptr; double thr_for = -1.0; uint32_t thr_rule = 0;   // per-query minimum score, cached per threshold (and rule)
     // hash buffers per (canonicalize, num_hashes); the kernel re-runs once per pm_search
     struct HashBuf { int canon; uint32_t nh; uint64_t* d; uint64_t epoch; };
     std::vector<HashBuf> hashes;
@@ -180,6 +180,10 @@ extern uint32_t g_single_launch;
 extern uint32_t g_wide_query;
 // pm_set_option("wide_query_split"): 0 = automatic number of workgroups that share a long query's steps, 1 = never split, n = force n
 extern uint32_t g_wq_split;
+// pm_set_option("cobs_threshold_rule"): how -t becomes a minimum score: 0 = ceil(t * k-mers) (default), 1 = floor, 2 = round
+extern uint32_t g_threshold_rule;
+// pm_set_option("cobs_tie_order"): 1 = documents of equal score are listed by DESCENDING index (default 0: ascending)
+extern uint32_t g_tie_desc;
 
 // pm_search.cpp: cobs' line order on records: (slot, query, count records first, score desc, doc asc)
 bool hit_less(const pm_hit_t& a, const pm_hit_t& b);

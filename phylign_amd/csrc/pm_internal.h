@@ -55,7 +55,7 @@ struct ScanArgs {
     uint32_t        wide_query; // 1: several lane groups of a workgroup share one query (k_scan<..., WQ>)
     uint32_t        wq_groups;  // ... at most this many (power of two, 4 ... 256; capped by 256 / lanes per row)
     uint32_t        nsplit;     // wide-query form: workgroups (gridDim.z) that share the steps of a tile's queries (1 = none)
-    uint32_t        pad2_;
+    uint32_t        tie_desc;   // 1: documents of equal score are written by descending index (pm_set_option "cobs_tie_order")
     uint4*          split_slabs;   // nsplit > 1: [workgroup (x, y)][z][plane][256 / groups per query] partial count planes
     uint32_t*       split_cnt;     // ... and one arrival counter per workgroup (x, y), zeroed ahead of the launch
 };
@@ -74,6 +74,7 @@ hipError_t launch_restride(const uint8_t* src, uint64_t row_bytes, uint8_t* dst,
                            uint64_t n_rows, hipStream_t st);
 hipError_t launch_publish(const unsigned long long* src, unsigned long long* dst_mapped, int n, hipStream_t st);
 hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* src, uint4* dst, hipStream_t st);
-hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst, hipStream_t st);
+hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst,
+                             uint32_t tie_desc, hipStream_t st);
 
 }  // namespace pm

@@ -673,7 +673,10 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
             excl = in2 - cnt;
             lvl = (uint32_t)__shfl((int)in2, (int)(gfirst + g - 1u), 64);
         }
-        uint64_t pos = run_base + 1u + emitted + excl;
+        // rank of my first document among the lvl documents of this score level, ascending by document index; the level
+        // is written in that order, or mirrored ("cobs_tie_order" 1: equal scores by descending document)
+        uint32_t rank = excl;
+        const uint64_t lvl_base = run_base + 1u + emitted;
         const uint32_t mw[4] = {M.x, M.y, M.z, M.w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -681,9 +684,10 @@ __global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
             while (m != 0u) {
                 const int bit = __ffs((int)m) - 1;
                 m &= m - 1u;
+                const uint64_t pos = lvl_base + (a.tie_desc ? lvl - 1u - rank : rank);
                 if (pos < a.hit_cap)
                     a.hits[pos] = make_uint4(q, bd.doc_base + (uint32_t)(doc0 + 32u * w + (uint32_t)bit), s, bd.slot);
-                ++pos;
+                ++rank;
             }
         }
         emitted += lvl;
@@ -822,7 +826,7 @@ hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* 
 // `runs`, -}; run = {first source record (behind the count record), records, -, -}.  One workgroup per group.
 __global__ __launch_bounds__(256) void k_merge_runs(const uint4* __restrict__ groups, uint32_t n_groups,
                                                      const uint4* __restrict__ runs, const uint4* __restrict__ src,
-                                                     uint4* __restrict__ dst)
+                                                     uint4* __restrict__ dst, uint32_t tie_desc)
 {
     constexpr uint32_t kStage = 512;
     __shared__ uint32_t s_begin[kStage], s_len[kStage], s_doc[kStage];
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(256) void k_merge_runs(const uint4* __restrict__ gr
                     uint32_t lo = 0, hi = ol;                      // records of run o with score > sc (scores descend)
                     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (src[(uint64_t)ob + m].z > sc) lo = m + 1; else hi = m; }
                     pos += lo;
-                    if (od < d0) {                                 // lower documents: their equal scores come first
+                    if (tie_desc ? od > d0 : od < d0) {            // lower documents: their equal scores come first (higher: "cobs_tie_order" 1)
                         uint32_t lo2 = lo, hi2 = ol;
                         while (lo2 < hi2) { const uint32_t m = (lo2 + hi2) >> 1; if (src[(uint64_t)ob + m].z >= sc) lo2 = m + 1; else hi2 = m; }
                         pos += lo2 - lo;
@@ -864,9 +868,10 @@ __global__ __launch_bounds__(256) void k_merge_runs(const uint4* __restrict__ gr
         }
     }
 }
-hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst, hipStream_t st) {
+hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst,
+                             uint32_t tie_desc, hipStream_t st) {
     if (n_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_runs, dim3(n_groups < 65536u ? n_groups : 65536u), dim3(256), 0, st, groups, n_groups, runs, src, dst);
+    hipLaunchKernelGGL(k_merge_runs, dim3(n_groups < 65536u ? n_groups : 65536u), dim3(256), 0, st, groups, n_groups, runs, src, dst, tie_desc);
     return hipGetLastError();
 }
 

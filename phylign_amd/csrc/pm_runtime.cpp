@@ -22,6 +22,8 @@ uint32_t g_count_fetched = 0;
 uint32_t g_single_launch = 0;
 uint32_t g_wide_query = 0;
 uint32_t g_wq_split = 0;
+uint32_t g_threshold_rule = 0;
+uint32_t g_tie_desc = 0;
 
 // ------------------------------------------------------------- worker pool
 namespace {
@@ -187,13 +189,27 @@ extern "C" int pm_set_option(const char* name, int64_t value) try {
         g_wq_split = (uint32_t)value;
         return PM_OK;
     }
+    // the two rules of `cobs query` that nothing in the reference repository pins: switchable, so
+    // that the day a cobs 0.2.1 binary says otherwise (tools/pin_against_cobs.sh) no code changes
+    if (strcmp(name, "cobs_threshold_rule") == 0) {
+        if (value < 0 || value > 2) return fail(PM_EINVAL, "cobs_threshold_rule takes 0 (ceil), 1 (floor) or 2 (round half up)");
+        g_threshold_rule = (uint32_t)value;
+        return PM_OK;
+    }
+    if (strcmp(name, "cobs_tie_order") == 0) {
+        if (value < 0 || value > 1) return fail(PM_EINVAL, "cobs_tie_order takes 0 (equal scores by ascending document) or 1 (descending)");
+        g_tie_desc = (uint32_t)value;
+        return PM_OK;
+    }
     return fail(PM_EINVAL, "unknown option '%s'", name);
 } PM_GUARD_END
 
 // The ONE place that turns `-t` into a minimum score (cobs counts_to_result):
 // ceil(threshold * num_terms) in IEEE double.  config.yaml:20 -> Snakefile:410.
+// pm_set_option("cobs_threshold_rule"): 1 = truncation, 2 = round half up -- the alternatives a real cobs may turn out to use.
 extern "C" uint32_t pm_threshold_terms(double threshold, uint64_t num_terms) {
-    double t = std::ceil(threshold * (double)num_terms);
+    const double x = threshold * (double)num_terms;
+    double t = g_threshold_rule == 1 ? std::floor(x) : (g_threshold_rule == 2 ? std::floor(x + 0.5) : std::ceil(x));
     if (!(t > 0)) return 0;
     if (t > 4294967295.0) return 4294967295u;
     return (uint32_t)t;

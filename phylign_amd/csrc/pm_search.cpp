@@ -117,6 +117,7 @@ struct pm_result {
     pm_queries* q = nullptr;
     double threshold = 0;
     uint32_t nb_best = 0, slot_base = 0;
+    uint32_t tie_desc = 0;                        // the "cobs_tie_order" in force when the search was queued
     std::vector<pm_qpart_t> parts;                // empty, or the part of the queries every index is searched with
     // device output
     uint4* d_hits = nullptr;
@@ -309,13 +310,13 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
         ws->uploaded.assign(ws->h_desc, ws->h_desc + (1 + kNumClasses) * dcap);
     }
     // per-query minimum score, cached on the query set per threshold value
-    if (nq && (!q->d_thr || q->thr_for != r->threshold)) {
+    if (nq && (!q->d_thr || q->thr_for != r->threshold || q->thr_rule != g_threshold_rule)) {
         std::vector<uint32_t> thr(nq);
         for (size_t i = 0; i < nq; ++i) thr[i] = r->threshold == 0.0 ? 0u : pm_threshold_terms(r->threshold, q->n_terms[i]);
         if (!q->d_thr) HIPCHK(hipMalloc((void**)&q->d_thr, nq * 4));
         HIPCHK(hipStreamSynchronize(st));                 // an earlier search in flight may still read the old values
         HIPCHK(hipMemcpy(q->d_thr, thr.data(), nq * 4, hipMemcpyHostToDevice));
-        q->thr_for = r->threshold;
+        q->thr_for = r->threshold; q->thr_rule = g_threshold_rule;
     }
     // measurement option: sharded counters of the algorithmic bytes the scan really gathered
     size_t n_launch_max = 0;
@@ -352,7 +353,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             a.tiles = 0; a.total_blocks = 0;
             a.wq_groups = use_wq[(size_t)(&g - groups.data()) * kNumClasses + (size_t)c];
             a.wide_query = a.wq_groups ? 1u : 0u;
-            a.nsplit = 1; a.pad2_ = 0; a.split_slabs = nullptr; a.split_cnt = nullptr;
+            a.nsplit = 1; a.tie_desc = r->tie_desc; a.split_slabs = nullptr; a.split_cnt = nullptr;
             if (g.g > 0 && g.has_parts) {
                 // the slice of this query class holds every unit's query range; a unit with fewer queries leaves tiles empty
                 a.batches = ws->d_desc + (size_t)(1 + c) * dcap + desc_off;
@@ -529,6 +530,7 @@ extern "C" int pm_search_async_parts(pm_index_t* const* idx, size_t n_idx, pm_qu
     r->idx.assign(idx, idx + n_idx);
     r->q = q; r->threshold = threshold; r->nb_best = nb_best_hits; r->slot_base = slot_base;
     if (parts) r->parts.assign(parts, parts + n_idx);
+    r->tie_desc = g_tie_desc;
     uint64_t hint;
     { std::lock_guard<std::mutex> lk(g_pool_mu); hint = g_ctx.hit_hint; }
     // first guess of the record count: 48 per query (a read that matches its species' batch brings ~100 records after the
@@ -618,7 +620,7 @@ bool hit_less(const pm_hit_t& a, const pm_hit_t& b) {
     const bool am = a.doc == PM_DOC_COUNT, bm = b.doc == PM_DOC_COUNT;
     if (am != bm) return am;                              // count records lead their (slot, query) run
     if (a.score != b.score) return a.score > b.score;     // score descending
-    return a.doc < b.doc;                                 // then document index ascending
+    return g_tie_desc ? a.doc > b.doc : a.doc < b.doc;    // then document index ascending ("cobs_tie_order" 1: descending)
 }
 
 // Orders records by (slot, query, score desc, doc asc).  Large inputs: stable
@@ -766,7 +768,7 @@ static int ensure_ordered(pm_result* r) {
         { int rc = take_hit_buffer(m_groups.size() + m_runs.size(), &mp); if (rc) return done(rc); }
         hipError_t e = hipMemcpyAsync(mp.p, m_groups.data(), m_groups.size() * sizeof(uint4), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(mp.p + m_groups.size(), m_runs.data(), m_runs.size() * sizeof(uint4), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = launch_merge_runs(mp.p, (uint32_t)m_groups.size(), mp.p + m_groups.size(), r->d_hits, r->d_ord.p, st);
+        if (e == hipSuccess) e = launch_merge_runs(mp.p, (uint32_t)m_groups.size(), mp.p + m_groups.size(), r->d_hits, r->d_ord.p, r->tie_desc, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         give_hit_buffer(mp);
         if (e != hipSuccess) return done(fail(PM_EHIP, "merging multi-run groups: %s", hipGetErrorString(e)));

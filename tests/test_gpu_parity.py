@@ -60,9 +60,26 @@ CASES = [
 ]
 
 
+@pytest.fixture
+def rules(request, pm, oracle):
+    """(cobs_threshold_rule, cobs_tie_order) set on both the product and the oracle for one test, defaults restored"""
+    thr_rule, tie = request.param
+    pm.set_option("cobs_threshold_rule", thr_rule)
+    pm.set_option("cobs_tie_order", tie)
+    oracle.set_rules(thr_rule, tie)
+    yield request.param
+    pm.set_option("cobs_threshold_rule", 0)
+    pm.set_option("cobs_tie_order", 0)
+    oracle.set_rules(0, 0)
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "D%d_S%d_q%dx%d_k%d_c%d_h%d_t%s" % c)
 @pytest.mark.parametrize("layout", [1, 2])
-def test_query_text_bit_exact(pm, oracle, case, layout):
+@pytest.mark.parametrize("rules", [(0, 0), (1, 0), (2, 1), (0, 1)], indirect=True, ids=["ceil_asc", "floor_asc", "round_desc", "ceil_desc"])
+def test_query_text_bit_exact(pm, oracle, case, layout, rules):
+    """the two `cobs query` rules nothing pins -- how -t becomes a minimum score, how equal scores are listed -- are
+    switches on both sides (pm_set_option / oracle.set_rules): whichever a real cobs 0.2.1 turns out to use
+    (tools/pin_against_cobs.sh), this test already covers it.  Default: ceil, ascending document."""
     n_docs, S, nq, qlen, k, canon, nh, thr = case
     rng = np.random.default_rng(hash(case) % (2**32))
     queries = [(f"read{i} comment {i}" if i % 3 == 0 else f"read{i}", rand_seq(rng, qlen)) for i in range(nq)]
@@ -317,8 +334,10 @@ def test_on_device_top_n_with_ties(pm, oracle, n_docs):
     (128, 2500, [600, 500, 400], [2, 1, 3]),
     (2048, 20000, [300, 200], [1, 1]),               # 16384 documents per sub-index: column slabs
 ])
-def test_compact_index_text_bit_exact(pm, oracle, page, n_docs, sigs, nhs, tmp_path):
-    """COMPACT_INDEX files: sub-indexes with their own signature sizes and hash counts"""
+@pytest.mark.parametrize("rules", [(0, 0), (2, 1)], indirect=True, ids=["ceil_asc", "round_desc"])
+def test_compact_index_text_bit_exact(pm, oracle, page, n_docs, sigs, nhs, tmp_path, rules):
+    """COMPACT_INDEX files: sub-indexes with their own signature sizes and hash counts
+    (under both settings of the unpinned rules: the runs of several sub-indexes are merged on the device)"""
     from helpers import doc_names
     from phylign_amd import postprocess as P
     rng = np.random.default_rng(page + n_docs)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Inputs of tools/pin_against_cobs.sh (seeded, no GPU, no oracle): a genome-like species batch as one FASTA per strain --
+"""Inputs of tools/pin_against_cobs.sh (seeded, numpy only): a genome-like species batch as one FASTA per strain --
 what `cobs classic-construct` takes -- and query files whose scores straddle every rule that nothing in the reference
 pins: reads of 151 bp (121 k-mers: ceil(0.7 x 121) = 85 but floor = 84), 150 bp and 31-40 bp at error rates
 0-12 %, documents that are identical over the read (equal scores -> tie order), a read shorter than k and one with an N."""

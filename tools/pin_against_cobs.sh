@@ -5,7 +5,7 @@
 #
 #   conda create -n cobs -c bioconda cobs=0.2.1 && conda activate cobs      (any machine with network)
 #   bash tools/pin_against_cobs.sh                                          (repo root; no GPU needed for the capture)
-#   python -m pytest tests/test_cobs_pin.py -q                              (CPU: oracle; with -m gpu on an MI355X: product)
+#   python -m pytest tests/test_cobs_pin.py -q                              (CPU: the checker; with -m gpu on an MI355X: the product)
 #
 # What is captured (all small, committed as data):
 #   tests/golden/cobs/genomes/*.fa          24 genome-like strains of one species (tools/make_pin_inputs.py, seeded)
@@ -18,7 +18,7 @@
 #   tests/golden/cobs/edge_*.txt            stdout / exit status for a read shorter than k and a read with an N
 #   tests/golden/cobs/cobs_version.txt
 # The test then says which setting of the two switchable rules (cobs_threshold_rule x cobs_tie_order) reproduces the
-# text byte for byte; if it is not the default, change the defaults in pm_runtime.cpp / cobs_oracle.c (one line each).
+# text byte for byte; if it is not the default, change the defaults in pm_runtime.cpp and in the checker under tests (one line each).
 set -euo pipefail
 cd "$(dirname "$0")/.."
 G=tests/golden/cobs

@@ -131,7 +131,13 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * through LDS; the threshold bound is off in that form); 1 = always, 2 = never.
  * "wide_query_split" (default 0 = automatic): in that form, how many workgroups share the steps of one query
  * (a dozen chromosome-sized queries would otherwise leave most of the chip idle); 1 = never, n = force n.
- * "single_launch" (default 0): rows of every width up to 1024 B share one launch. */
+ * "single_launch" (default 0): rows of every width up to 1024 B share one launch.
+ * "merge_counting_sort" (default 1): hit lists written as several runs (rows wider than 1024 B, compact sub-indexes) are
+ * merged by a counting sort on the score; 0 = the general pairwise form for every group (same result).
+ * "cobs_threshold_rule" (default 0) / "cobs_tie_order" (default 0): the two rules of `cobs query` that no file of the
+ * reference pins -- how -t becomes a minimum score: 0 = ceil(t x k-mers), 1 = floor, 2 = round half up; how documents of
+ * equal score are listed: 0 = ascending document index, 1 = descending.  The defaults are upstream's as recalled
+ * (DESIGN.md section 5); tools/pin_against_cobs.sh checks them against a real cobs 0.2.1. */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);

@@ -184,6 +184,9 @@ extern uint32_t g_wq_split;
 extern uint32_t g_threshold_rule;
 // pm_set_option("cobs_tie_order"): 1 = documents of equal score are listed by DESCENDING index (default 0: ascending)
 extern uint32_t g_tie_desc;
+// pm_set_option("merge_counting_sort") (default 1): (slot, query) groups written as several runs are merged by the
+// O(records + runs) counting sort where it applies; 0 = always the O(records x runs x log) form (A/B, tests)
+extern uint32_t g_merge_hist;
 
 // pm_search.cpp: cobs' line order on records: (slot, query, count records first, score desc, doc asc)
 bool hit_less(const pm_hit_t& a, const pm_hit_t& b);

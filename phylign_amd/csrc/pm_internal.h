@@ -76,5 +76,11 @@ hipError_t launch_publish(const unsigned long long* src, unsigned long long* dst
 hipError_t launch_permute_runs(const uint4* plan, uint32_t n_plan, const uint4* src, uint4* dst, hipStream_t st);
 hipError_t launch_merge_runs(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst,
                              uint32_t tie_desc, hipStream_t st);
+// the O(records + runs) form for groups whose scores are at most merge_hist_max_score() and that have at most
+// merge_hist_max_runs() runs
+hipError_t launch_merge_runs_hist(const uint4* groups, uint32_t n_groups, const uint4* runs, const uint4* src, uint4* dst,
+                                  uint32_t tie_desc, hipStream_t st);
+uint32_t merge_hist_max_score();
+uint32_t merge_hist_max_runs();
 
 }  // namespace pm

@@ -24,6 +24,7 @@ uint32_t g_wide_query = 0;
 uint32_t g_wq_split = 0;
 uint32_t g_threshold_rule = 0;
 uint32_t g_tie_desc = 0;
+uint32_t g_merge_hist = 1;
 
 // ------------------------------------------------------------- worker pool
 namespace {
@@ -196,6 +197,7 @@ extern "C" int pm_set_option(const char* name, int64_t value) try {
         g_threshold_rule = (uint32_t)value;
         return PM_OK;
     }
+    if (strcmp(name, "merge_counting_sort") == 0) { g_merge_hist = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "cobs_tie_order") == 0) {
         if (value < 0 || value > 1) return fail(PM_EINVAL, "cobs_tie_order takes 0 (equal scores by ascending document) or 1 (descending)");
         g_tie_desc = (uint32_t)value;

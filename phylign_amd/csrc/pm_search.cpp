@@ -726,7 +726,7 @@ static int ensure_ordered(pm_result* r) {
     sort_directory(dir);
     uint64_t o = 0;
     size_t np = 0, k = 0;
-    std::vector<uint4> m_groups, m_runs;
+    std::vector<uint4> m_groups, m_runs;          // groups of several runs; .w of a group: 1 = the counting-sort merge applies
     r->slot_first.assign(r->idx.size() + 1, 0);
     size_t next_slot = 0;                          // slots up to here have their first record noted
     while (k < dir.size()) {
@@ -744,7 +744,9 @@ static int ensure_ordered(pm_result* r) {
         } else {
             // several runs of one (slot, query): merged into one ordered list by k_merge_runs (count records dropped:
             // such groups are never cut on the GPU)
-            m_groups.push_back(make_uint4((uint32_t)o, (uint32_t)(e - k), (uint32_t)m_runs.size(), 0u));
+            // a score is at most the query's k-mer count: short queries with few runs take the O(records + runs) merge
+            const bool hist = r->q->n_terms[dir[k].query] <= merge_hist_max_score() && e - k <= merge_hist_max_runs();
+            m_groups.push_back(make_uint4((uint32_t)o, (uint32_t)(e - k), (uint32_t)m_runs.size(), hist ? 1u : 0u));
             for (size_t j = k; j < e; ++j) {
                 const uint32_t len = dir[j].len & 0x7FFFFFFFu;
                 m_runs.push_back(make_uint4(dir[j].begin + 1u, len, 0u, 0u));
@@ -764,11 +766,17 @@ static int ensure_ordered(pm_result* r) {
     OCHK(hipStreamSynchronize(st));
     // groups written as several runs (rows wider than 1024 bytes, compact sub-indexes) are merged on the device
     if (!m_groups.empty()) {
+        // the groups of the counting-sort merge first, the others behind them
+        std::stable_partition(m_groups.begin(), m_groups.end(), [](const uint4& g) { return g.w != 0u; });
+        size_t n_hist = 0;
+        while (n_hist < m_groups.size() && m_groups[n_hist].w) ++n_hist;
+        if (g_merge_hist == 0) n_hist = 0;
         HitBuf mp{nullptr, 0};
         { int rc = take_hit_buffer(m_groups.size() + m_runs.size(), &mp); if (rc) return done(rc); }
         hipError_t e = hipMemcpyAsync(mp.p, m_groups.data(), m_groups.size() * sizeof(uint4), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(mp.p + m_groups.size(), m_runs.data(), m_runs.size() * sizeof(uint4), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = launch_merge_runs(mp.p, (uint32_t)m_groups.size(), mp.p + m_groups.size(), r->d_hits, r->d_ord.p, r->tie_desc, st);
+        if (e == hipSuccess) e = launch_merge_runs_hist(mp.p, (uint32_t)n_hist, mp.p + m_groups.size(), r->d_hits, r->d_ord.p, r->tie_desc, st);
+        if (e == hipSuccess) e = launch_merge_runs(mp.p + n_hist, (uint32_t)(m_groups.size() - n_hist), mp.p + m_groups.size(), r->d_hits, r->d_ord.p, r->tie_desc, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         give_hit_buffer(mp);
         if (e != hipSuccess) return done(fail(PM_EHIP, "merging multi-run groups: %s", hipGetErrorString(e)));

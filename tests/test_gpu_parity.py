@@ -423,3 +423,43 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
         hits = res.hits()
         for s, (index, _, _) in enumerate(cases):
             assert pm.format_hits(ixs[s], q, hits, slot=5 + s) == oracle.query_file(index, fasta, thr), shapes[s]
+
+
+@pytest.mark.parametrize("rules", [(0, 0), (0, 1)], indirect=True, ids=["asc", "desc"])
+def test_many_runs_per_query_merge_counting_sort_equals_pairwise(pm, oracle, rules):
+    """a compact index of 157 sub-indexes (128 documents each): every (query, index) hit list arrives as up to 157 runs.
+    The counting-sort merge (scores below 4096, the default) and the general pairwise merge give the same records, equal
+    to the oracle's text; a 6-kbp query (score range beyond the histogram) takes the pairwise form inside the same search"""
+    import time
+    from helpers import doc_names
+    rng = np.random.default_rng(157)
+    page, n_docs = 16, 20000
+    per = page * 8
+    n_parts = (n_docs + per - 1) // per
+    sigs, nhs = [int(rng.integers(300, 600)) for _ in range(n_parts)], [1] * n_parts
+    queries = [(f"m{i}", rand_seq(rng, 150)) for i in range(40)] + [("long", rand_seq(rng, 6000))]
+    mats = []
+    for p, S in enumerate(sigs):
+        bits = rng.random((S, per)) < 0.3
+        if p * per + per > n_docs:
+            bits[:, n_docs - p * per:] = False
+        mats.append(np.packbits(bits, axis=1, bitorder="little"))
+    index = oracle.make_compact(31, 1, page, sigs, nhs, doc_names(rng, n_docs), mats)
+    fasta = "".join(f">{h}\n{s}\n" for h, s in queries).encode()
+    ix = pm.Index.load_mem(index)
+    q = pm.Queries(fasta)
+    try:
+        for thr in (0.0, 0.3):
+            got, took = {}, {}
+            for mode in (1, 0):
+                pm.set_option("merge_counting_sort", mode)
+                res = pm.search([ix], q, thr)
+                t0 = time.perf_counter()
+                got[mode] = res.hits()
+                took[mode] = time.perf_counter() - t0
+            assert np.array_equal(got[0], got[1]), thr
+            assert len(got[1]) > 41 * 100
+            assert pm.format_hits(ix, q, got[1]) == oracle.query_file(index, fasta, thr)
+            print(f"thr {thr}: {len(got[1])} records, ordering + read-back {took[1] * 1e3:.1f} ms (counting sort) vs {took[0] * 1e3:.1f} ms (pairwise)")
+    finally:
+        pm.set_option("merge_counting_sort", 1)

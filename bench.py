@@ -207,8 +207,15 @@ def main():
         # functional check on one GPU, or a launcher that already narrowed the visible devices per rank
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: ONE rank walks the whole N > 1 code path over a real process group -- RCCL collectives on device
+    # tensors (gather of the packed records, all_gather of the timings, all_reduce, barrier) with a world of one: the
+    # plumbing that an 8-GPU run uses, on the one GPU a test box has
+    multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            from phylign_amd.launch import free_port
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -269,7 +276,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -309,7 +316,7 @@ def main():
         # orders the run directory, k_permute_runs moves the runs); ranks own disjoint, increasing slot
         # ranges, so the rank-order concatenation that the gather produces on rank 0 is globally ordered
         host = None
-        if world == 1 and not force_gather:
+        if not multi and not force_gather:
             host = res.hits(copy=False)                    # view of the library's pinned buffer (lives as long as `res`)
             t_c = time.perf_counter()
         elif pg_dev == "cuda":
@@ -380,7 +387,7 @@ def main():
         elapsed = time.perf_counter() - t_start
         rank_elapsed = [elapsed]
         rank_phase = [[phase["queue"], phase["wait"], phase["host"], phase["gather"], packed.waited_s]]
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed] + rank_phase[0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)
@@ -509,7 +516,7 @@ def main():
 
     # ---- who took part (N > 1): a real all_reduce on device tensors counts the RCCL ranks, every rank reports the
     # GPU that holds its matrices and its own time for the K steps
-    participants = {"backend": backend if world > 1 else None, "rccl_ranks": None,
+    participants = {"backend": backend if multi else None, "rccl_ranks": None,
                     "rank_ms_per_step": [e / args.steps * 1e3 for e in run_head["rank_elapsed"]],
                     # host time per step and rank: queueing the launches, waiting for the GPU, ordering the runs on the device,
                     # the gather of hit records (root: until every rank's records are on its host; others: queueing the send),
@@ -517,7 +524,7 @@ def main():
                     "rank_host_ms": [dict(zip(("queue_launches", "wait_for_gpu", "run_order", "hit_gather", "send_buffer_wait"),
                                               [round(v / args.steps * 1e3, 4) for v in ph_])) for ph_ in run_head["rank_phase"]],
                     "rank_devices": [indexes[0].device if indexes else local_rank]}
-    if world > 1:
+    if multi:
         ddev = "cuda" if backend == "nccl" else "cpu"
         one = torch.ones(1, dtype=torch.int32, device=ddev)
         dist.all_reduce(one)
@@ -564,7 +571,7 @@ def main():
             clustered["threshold_bound"]["speed_vs_fetch_all_rows"] = (clustered["threshold_bound"]["value"] /
                                                                        clustered["fetch_all_rows"]["value"])
         except Exception as e:                                       # an optional leg never costs the headline line
-            if world > 1:
+            if multi:
                 raise
             log(f"[bench] clustered leg failed: {e!r}")
             clustered = {"error": repr(e)}
@@ -824,7 +831,7 @@ def main():
         h["slot"] = pos_of_slot[h["slot"]]
         np.save(args.dump_hits, pm.sort_hits(np.ascontiguousarray(h)))
     # every rank learns the verdict and leaves together (no rank waits in a barrier for one that exited)
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
@@ -836,7 +843,7 @@ def main():
         out["cpu_baseline"] = None
     if ok and rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:

@@ -12,7 +12,7 @@ def gather_hits(local, dst=0, group=None):
     """local: int32 tensor [n, 4] of pm_hit_t records (device tensor with nccl,
     CPU tensor with gloo).  Returns the concatenation over ranks in rank order
     on `dst`, None elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     assert local.dtype == torch.int32 and local.dim() == 2 and local.shape[1] == 4
@@ -62,7 +62,8 @@ class PackedGather:
         self.packs = [torch.zeros((self.cap + 1, 4), dtype=torch.int32, device=device) for _ in range(max(1, depth))]
         self.sent = [None] * len(self.packs)         # event behind the last collective that read packs[i]
         self.turn = 0
-        self.recv = [torch.zeros_like(self.packs[0]) for _ in range(self.world)] if self.rank == 0 and self.world > 1 else None
+        self.active = dist.is_initialized()          # a process group of ONE rank still goes through the collective
+        self.recv = [torch.zeros_like(self.packs[0]) for _ in range(self.world)] if self.rank == 0 and self.active else None
         self.waited_s = 0.0                          # host time spent waiting for a buffer to come free (should stay ~0)
 
     @property
@@ -87,7 +88,7 @@ class PackedGather:
         it exceeds cap and `overflow` (int32 [count, 4]) holds all records."""
         assert dst == 0
         pack = self.packs[self.turn]
-        if self.world == 1:
+        if not self.active:
             return overflow if count > self.cap else pack[1:1 + count]
         self.records_view()                           # (no-op when the caller filled the buffer through records_view())
         pack[0, 0] = int(count)

@@ -496,12 +496,17 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("PHYLIGN_DIST_BACKEND", "nccl")
-    if world > 1:                                                   # torch only for the multi-rank exchange
+    # PHYLIGN_FORCE_DIST=1: one rank walks the multi-rank exchange over a real process group of one (RCCL on device
+    # tensors): the plumbing of an 8-GPU run on the one GPU a test box has
+    multi = world > 1 or bool(os.environ.get("PHYLIGN_FORCE_DIST"))
+    if multi:                                                       # torch only for the multi-rank exchange
         import torch
         import torch.distributed as dist
         from .dist import gather_hits
         local_rank = bind_rank_to_gpu(local_rank, torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -581,7 +586,7 @@ def main(argv=None):
     # batch's number in that rank's merge), rank 0 adds the parts and emits
     t_f = time.perf_counter()
     if args.filter_out:
-        if world > 1:
+        if multi:
             ex = merge.export()
             t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
             if backend == "nccl":
@@ -607,7 +612,7 @@ def main(argv=None):
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
             report["filter_fasta_bytes"] = merge.emit_to(args.filter_out)
     report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     report["host_ram_plan"] = {"loaders": args.loaders, "budget_mb": budget_mb,

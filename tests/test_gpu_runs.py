@@ -484,3 +484,37 @@ def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
                        ["--dump-hits", str(plain)], capture_output=True, env=env8)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert np.array_equal(np.load(plain), a)
+
+
+def test_one_rank_walks_the_rccl_path(pm, oracle, tmp_path):
+    """BENCH_FORCE_DIST / PHYLIGN_FORCE_DIST: a process group of ONE rank over RCCL (backend nccl) -- the collectives of
+    the N > 1 path run on device tensors on real hardware: the packed gather of the ordered records with its alternating
+    send buffers, all_gather of the timings, all_reduce, barrier; the records equal the plain run's.  (Two RCCL ranks
+    cannot share one GPU, so this is as far as a 1-GPU box can take the RCCL plumbing; rank layouts are covered with
+    gloo.)"""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "BENCH_DIST_BACKEND", "PHYLIGN_DIST_BACKEND"):
+        env.pop(k, None)
+    common = ["--steps", "3", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline", "--only-headline"]
+    plain, forced = tmp_path / "plain.npy", tmp_path / "forced.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(plain)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(forced)], capture_output=True,
+                       env=dict(env, BENCH_FORCE_DIST="1"))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    part = line["participants"]
+    assert part["backend"] == "nccl" and part["rccl_ranks"] == 1 and part["rank_devices"] == [0]
+    assert part["rank_host_ms"][0]["hit_gather"] > 0
+    assert np.array_equal(np.load(plain), np.load(forced)) and len(np.load(plain)) > 50
+    # the stage: merge export -> RCCL gather -> rank 0 emits
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_cli import _check_stage_outputs, _stage_fixture
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+                        "--cobs-dir", str(tmp_path / "cobs"), "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"),
+                        "--out-dir", str(tmp_path / "03_match"), "--nb-best-hits", "3",
+                        "--filter-out", str(tmp_path / "04_filter" / "Q.fa")], capture_output=True, env=dict(env, PHYLIGN_FORCE_DIST="1"))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the PMC summaries of tools/run_profiles.sh:
-    python3 tools/make_pmc_traffic.py <pmc_fetch_all.txt> <pmc_bound.txt> > profiles/pmc_traffic.json
+    python3 tools/make_pmc_traffic.py <pmc_fetch_all.txt> <pmc_bound.txt> [round] > profiles/pmc_traffic.json
 HBM bytes per launch of every k_scan instantiation = 128 x TCC_EA0_RDREQ_128B + 64 x _64B + 32 x _32B (the request
 sizes are counted, not assumed) + WRITE_SIZE (KiB).  Stamped with the git blob id of pm_kernels.hip: bench.py
 reports `traffic: null` for any other kernel source."""
@@ -38,8 +38,8 @@ def parse(path):
     return out
 
 
-def main(fetch_all, bound):
-    res = {"round": 3, "pm_kernels_blob": blob(), "workload": "config3", "queries": 100000, "query_len": 150,
+def main(fetch_all, bound, rnd=4):
+    res = {"round": int(rnd), "pm_kernels_blob": blob(), "workload": "config3", "queries": 100000, "query_len": 150,
            "how": "tools/run_profiles.sh: rocprofv3 --kernel-trace --pmc passes (one counter group per run) over `bench.py --steps 1 "
                   "--warmup 0 --no-cpu-baseline --only-headline --no-pipeline`; bytes = 128 x TCC_EA0_RDREQ_128B_sum + 64 x "
                   "TCC_EA0_RDREQ_64B_sum + 32 x TCC_EA0_RDREQ_32B_sum + 1024 x WRITE_SIZE", "kernels": {}}
@@ -59,4 +59,4 @@ def main(fetch_all, bound):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

@@ -106,7 +106,7 @@ static hipError_t launch_synth(uint8_t* dst, uint64_t stride, uint64_t n_rows, u
 // Ceiling probe: the same access pattern as k_scan (random rows, 16 B per lane,
 // G lanes per row, 8 gathers in flight per lane) with the counting replaced by
 // one XOR per load.  Used only to measure what the memory system delivers for
-// this pattern; not part of the matching path.
+// this pattern (profiles/r03/NOTES.md section 6); not part of the matching path.
 template <int G, int U>
 __global__ __launch_bounds__(256) void k_probe_gather(const uint8_t* __restrict__ matrix, uint64_t stride,
                                                        uint64_t n_rows, uint64_t lookups_per_group, uint32_t* sink,
@@ -457,7 +457,7 @@ extern "C" int pm_bench_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
 }
 
 // A resident classic index written back as a .cobs_classic file (header in the first of the two field orders the
-// product's reader accepts, DESIGN.md section 5): lets a measurement put 661k-SHAPED index files -- and their .xz -- on
+// product's reader accepts, DESIGN.md section 6): lets a measurement put 661k-SHAPED index files -- and their .xz -- on
 // disk for the cold / cached / resident timings of the stage (tools/e2e_cold_warm.py).
 extern "C" int pm_bench_index_save(const pm_index_t* ix, const char* path) {
     if (!ix || !path) return bfail(PM_EINVAL, "bad argument");

@@ -10,7 +10,7 @@
 // The consumers only ever inflate the stream (scripts/filter_queries.py:46 through xopen; `gzip -dc`), so the
 // contract is the decoded bytes, and RFC 1951 / 1952 validity -- tests/test_golden_cpu.py decodes every shape with
 // Python's gzip.  zlib level 1 spends ~10 ns per byte on this text, this encoder 1-2; at a million reads deflate
-// was the largest single cost of a clustered 03_match run.
+// was the largest single cost of a clustered 03_match run (profiles/r03/NOTES.md section 6, config 5).
 #include "pm_host.h"
 #include <zlib.h>
 

@@ -190,7 +190,7 @@ extern "C" int pm_set_option(const char* name, int64_t value) try {
         g_wq_split = (uint32_t)value;
         return PM_OK;
     }
-    // the two rules of `cobs query` that nothing in the reference repository pins (DESIGN.md section 5): switchable, so
+    // the two rules of `cobs query` that nothing in the reference repository pins (DESIGN.md section 6): switchable, so
     // that the day a cobs 0.2.1 binary says otherwise (tools/pin_against_cobs.sh) no code changes
     if (strcmp(name, "cobs_threshold_rule") == 0) {
         if (value < 0 || value > 2) return fail(PM_EINVAL, "cobs_threshold_rule takes 0 (ceil), 1 (floor) or 2 (round half up)");

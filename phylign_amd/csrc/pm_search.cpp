@@ -264,7 +264,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
             // automatic: always when the plain form could not fill the chip (< 1.5 x the 4 096 wave slots of
             // 4 waves/SIMD); narrow rows (one query per lane group of 1 ... 16 lanes) measure faster in this
             // form at any query count, but only while every row is fetched anyway -- the form gives up the
-            // threshold bound (tools/variant_longq.sh)
+            // threshold bound (tools/variant_longq.sh, profiles/r03/NOTES.md section 6)
             const bool few = waves < 6144;
             const bool narrow = groups[gi].g < 32;
             if (!(g_wide_query == 1 || few || (narrow && !g_threshold_bound))) continue;

@@ -382,7 +382,7 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
         if max_group <= 0 and len(mine) >= 16 and nc == 1:
             # four quarters instead of one group: the host part of a quarter (text, gzip, merge) overlaps the scans of the
             # next ones and only the last quarter's is left at the end (measured on 38 batches, 1 M reads: stage wall 0.22 /
-            # 0.17 / 0.17 / 0.15 s with 2 / 3 / 4 / 8 groups, match-only 0.131 -> 0.137 s: DESIGN.md section 6)
+            # 0.17 / 0.17 / 0.15 s with 2 / 3 / 4 / 8 groups, match-only 0.131 -> 0.137 s: profiles/r03/NOTES.md section 6)
             max_group = (len(mine) + 3) // 4
     with ThreadPoolExecutor(max_workers=max(1, loaders)) as pool:
         futures = [] if resident else [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# The config-4/5 end-to-end rows of DESIGN.md section 6 (GPU box, repo root):  bash tools/e2e_numbers.sh <outdir>
+# The config-4/5 end-to-end rows of profiles/r03/NOTES.md section 6 (GPU box, repo root):  bash tools/e2e_numbers.sh <outdir>
 set -u
 out=${1:-gpurun_out/e2e_now}
 mkdir -p $out

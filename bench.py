@@ -51,6 +51,15 @@ from phylign_amd.sysinfo import effective_cpus  # noqa: E402
 from phylign_amd.sysinfo import available_ram_gb as host_memory_gb  # noqa: E402
 
 
+def flush_c_stdio():
+    """fflush(NULL): whatever native libraries (RCCL's banner) left in C stdio buffers goes out now"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def kernel_blob_hash():
     """git blob id of the kernel source: PMC traffic figures are only valid for the code they were measured on"""
     import hashlib
@@ -217,8 +226,11 @@ def main():
             from phylign_amd.launch import free_port
             os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
+            # the per-step gather runs beside the NEXT step's scan, which fills every CU: RCCL's kernels go on a
+            # high-priority stream so that they are dispatched as soon as a wave slot frees instead of queueing behind it
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("BENCH_RCCL_HIGH_PRIORITY", "1") != "0")
             dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", local_rank), pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     pm.init(local_rank)
@@ -832,6 +844,10 @@ def main():
         np.save(args.dump_hits, pm.sort_hits(np.ascontiguousarray(h)))
     # every rank learns the verdict and leaves together (no rank waits in a barrier for one that exited)
     if multi:
+        # RCCL prints its version banner through C stdio, which is fully buffered when stdout is a file or a pipe: left
+        # alone it comes out at exit, BEHIND rank 0's JSON line.  Every rank pushes it out before the collective that
+        # precedes the line, so the line is the last thing on stdout.
+        flush_c_stdio()
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
@@ -842,6 +858,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if ok and rank == 0:
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

@@ -585,15 +585,20 @@ def main(argv=None):
     # ---- 04_filter: ONE gather of what every rank's merge kept (queries numbered through the whole file, slot = the
     # batch's number in that rank's merge), rank 0 adds the parts and emits
     t_f = time.perf_counter()
+    fph = {"export": 0.0, "gather": 0.0, "names": 0.0, "add": 0.0, "emit": 0.0}     # where the 04_filter end of the stage spends its time
     if args.filter_out:
         if multi:
+            t_a = time.perf_counter()
             ex = merge.export()
             t = torch.from_numpy(ex.view(np.int32).reshape(-1, 4).copy())
             if backend == "nccl":
                 t = t.cuda()
+            t_b = time.perf_counter()
             g = gather_hits(t, dst=0)
             meta = [None] * world if rank == 0 else None
             dist.gather_object((len(ex), report["merge_order"]), meta, dst=0)
+            t_c = time.perf_counter()
+            fph["export"], fph["gather"] = t_b - t_a, t_c - t_b
             if rank == 0:
                 allrec = g.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
                 off = 0
@@ -605,12 +610,19 @@ def main(argv=None):
                     cut = np.searchsorted(part["slot"], np.arange(len(r_order) + 1, dtype=np.uint32))
                     for k, b in enumerate(r_order):
                         if cut[k + 1] > cut[k]:
+                            t_n = time.perf_counter()
                             nix = names_index(pm, source, b)
+                            t_m = time.perf_counter()
                             merge.add(b, nix, part[cut[k]:cut[k + 1]], slot=k, nb_best_hits=-1, piece=-1)
                             nix.free()
+                            fph["names"] += t_m - t_n
+                            fph["add"] += time.perf_counter() - t_m
         if rank == 0:
+            t_e = time.perf_counter()
             os.makedirs(os.path.dirname(os.path.abspath(args.filter_out)), exist_ok=True)
             report["filter_fasta_bytes"] = merge.emit_to(args.filter_out)
+            fph["emit"] = time.perf_counter() - t_e
+    report["filter_phases_s"] = {k: round(v, 4) for k, v in fph.items()}
     report["filter_emit_s"] = round(time.perf_counter() - t_f, 3)
     if multi:
         dist.barrier()

@@ -518,3 +518,20 @@ def test_one_rank_walks_the_rccl_path(pm, oracle, tmp_path):
                         "--filter-out", str(tmp_path / "04_filter" / "Q.fa")], capture_output=True, env=dict(env, PHYLIGN_FORCE_DIST="1"))
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+
+
+@pytest.mark.parametrize("n_docs,S,layout", [(100, 70001, 1), (664, 50021, 2), (2300, 20011, 2), (4000, 150001, 2), (9000, 3001, 2)])
+def test_saved_index_file_is_the_resident_index(pm, oracle, tmp_path, n_docs, S, layout):
+    """the measurement aid that writes a resident index back as a .cobs_classic file (tools/e2e_*.py put 661k-shaped
+    files on disk with it): the file is byte for byte what the checker builds from the same header, names and rows, and
+    loading it gives the same matrix (rows packed on the device, several 64 MiB chunks for the larger shapes)"""
+    from phylign_amd import bench_aids
+    ix = pm.Index.synth(5, n_docs, S, seed=661, layout=layout)
+    path = str(tmp_path / "b.cobs_classic")
+    bench_aids.index_save(ix, path)
+    with open(path, "rb") as f:
+        saved = f.read()
+    assert saved == np.asarray(_file_of(oracle, ix)).tobytes()
+    ix2 = pm.Index.load_file(path)
+    assert _names(ix2) == _names(ix) and np.array_equal(np.asarray(ix2.read_rows(0, S)), np.asarray(ix.read_rows(0, S)))
+    ix.free(); ix2.free()

@@ -136,7 +136,7 @@ def main():
                 "match_only_s_per_rank": [r["match_only_s"] for r in reps],
                 "e2e_s_per_rank": [r["e2e_s"] for r in reps],
                 "e2e_s": max(r["e2e_s"] for r in reps),
-                "filter_emit_s_rank0": reps[0].get("filter_emit_s"),
+                "filter_emit_s_rank0": reps[0].get("filter_emit_s"), "filter_phases_s_rank0": reps[0].get("filter_phases_s"),
                 "scan_launches": sum(r["scan_launches"] for r in reps),
                 "groups": sum(r["groups"] for r in reps)}
     rows["one_rank"] = summarise(rep1, wall1)

@@ -172,6 +172,8 @@ def main():
                          "queries (workload.assign_parts / pm_search_async_parts).  Off by default: on the 64 batches of config 3 "
                          "whole batches already balance 8 ranks to within the run-to-run noise (profiles/r04/NOTES.md)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before queueing the next one")
+    ap.add_argument("--pipeline-depth", type=int, default=0,
+                    help="steps queued ahead of the one the host is finishing (0 = 1 on one GPU, 2 with N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=24.0, help="timed CPU work of the baseline (2 partitions x 3 runs)")
     ap.add_argument("--cpu-sample-gb", type=float, default=0.0,
@@ -220,6 +222,7 @@ def main():
     # tensors (gather of the packed records, all_gather of the timings, all_reduce, barrier) with a world of one: the
     # plumbing that an 8-GPU run uses, on the one GPU a test box has
     multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (2 if multi else 1)
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -372,18 +375,21 @@ def main():
             res.free()
 
     def run_steps(n, groups=None, keep_last=False):
-        """n steps; unless --no-pipeline the kernels of step i+1 are queued before step i is finished"""
-        prev = None
+        """n steps; unless --no-pipeline the kernels of the next `depth` steps are queued before a step is finished (depth 1:
+        step i + 1 runs while the host orders / gathers step i; depth 2, the default for N > 1: a gather that comes back
+        late -- RCCL's kernels share the CUs with the running scan -- still finds a queued step behind the running one)"""
+        if args.no_pipeline:
+            for i in range(n):
+                finish_step(queue_step(), groups, keep_last and i == n - 1)
+            return
+        inflight = []
         for i in range(n):
-            cur = queue_step()
-            if args.no_pipeline:
-                finish_step(cur, groups, keep_last and i == n - 1)
-                continue
-            if prev is not None:
-                finish_step(prev, groups)
-            prev = cur
-        if prev is not None:
-            finish_step(prev, groups, keep_last)
+            inflight.append(queue_step())
+            if len(inflight) > depth:
+                finish_step(inflight.pop(0), groups)
+        while inflight:
+            res = inflight.pop(0)
+            finish_step(res, groups, keep_last and not inflight)
 
     def timed_run(bound, warmup, steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks"""
@@ -792,7 +798,7 @@ def main():
                    "batches_on_two_ranks": [{"batch": shapes[p_].batch, "index_GB": round(shapes[p_].index_bytes / 1e9, 3),
                                              "query_shares": {str(r_): [lo, hi, W.PART_DEN] for r_, part in enumerate(pparts)
                                                               for q_, lo, hi in part if q_ == p_}} for p_ in shared],
-                   "pipelined_steps": not args.no_pipeline},
+                   "pipelined_steps": not args.no_pipeline, "pipeline_depth": 0 if args.no_pipeline else depth},
         "scan_mode": (head + (": every signature row of every k-mer is gathered, like `cobs query` does -- independent "
                               "of the data; the product default (threshold_bound) is reported beside it"
                               if head == "fetch_all_rows" else

@@ -257,7 +257,7 @@ __device__ __forceinline__ u32x4 ld_row(const uint8_t* p) {
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
 // register budget of the wide counter classes (queries of 1 024 ... 2^24 k-mers hold 64 / 96 plane
-// registers): measured on 9.7 kbp / 100 kbp queries, see DESIGN.md section 6
+// registers): measured on 9.7 kbp / 100 kbp queries, see profiles/r03/NOTES.md section 6
 #ifndef PM_SCAN_WAVES_P16
 #define PM_SCAN_WAVES_P16 4
 #endif

@@ -16,7 +16,7 @@ for f in pm_runtime pm_index pm_queries pm_search pm_text pm_gzfast; do
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c pm_kernels.hip -o "$out/pm_kernels.o" &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=$san -o "$out/libphylign_match.so" "$out"/*.o -lz
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=$san -o "$out/libphylign_match.so" "$out"/*.o -lz -Wl,--version-script=exports.map
 cd ../..
 asan=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.$rt-x86_64.so" | head -1)
 PHYLIGN_MATCH_LIB="$out/libphylign_match.so" LD_PRELOAD="$asan" ASAN_OPTIONS=detect_leaks=0 TSAN_OPTIONS=report_signal_unsafe=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \

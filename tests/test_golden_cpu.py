@@ -1389,3 +1389,19 @@ def test_exceptions_on_pool_threads_become_error_codes(tmp_path):
                     "-x", "none"] + objs + ["-lz", "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, timeout=120)
     assert r.returncode == 0 and b"pool exceptions ok" in r.stdout, (r.returncode, r.stderr.decode()[-500:])
+
+
+@pytest.mark.parametrize("threshold", [0.7, 0.0, 1.0, 0.35])
+def test_oracle_equals_the_independent_python_restatement(oracle, threshold):
+    """whole texts: the C oracle against tests/independent.py -- python-xxhash, its own header writer (upstream's field
+    order), canonicalisation, scorer, ceil rule, order and grammar, written from SURVEY.md appendix A without looking at
+    oracle/ -- on genome-like indexes (24 ... 1 030 documents, k = 21 / 31, one and two hash functions, canonical and
+    not, reads in both orientations with 0 - 6 % errors, lengths k ... 151)"""
+    pytest.importorskip("xxhash")
+    import independent as I
+    for case in I.CASES:
+        seed, D, glen, k, num_hashes, canon = case
+        index, m, fasta, names, S, records = I.built_case(*case)
+        h = oracle.header_parse(index)
+        assert (h.term_size, h.n_docs, h.signature_size, h.num_hashes) == (k, D, S, num_hashes)
+        assert oracle.query_file(index, fasta, threshold) == I.query_text(records, names, m, k, num_hashes, S, threshold, canon), case

@@ -456,8 +456,9 @@ def main(argv=None):
                          "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for -- and no "
                          "more than fit --max-ram-gb at the decoder size the sizes table states: sizing.stage_plan)")
     ap.add_argument("--max-ram-gb", type=float, default=0.0,
-                    help="config.yaml max_ram_gb: host RAM the stage's xz decoders may hold together (the sizes table's third "
-                         "column per decoder, Snakefile:64-69; the index itself is in HBM).  0 = 80 %% of the RAM available now")
+                    help="config.yaml max_ram_gb: host RAM the stage's xz decoders may hold together on this node, all ranks "
+                         "(the sizes table's third column per decoder, Snakefile:64-69; the index itself is in HBM).  "
+                         "0 = 80 %% of the RAM available now")
     ap.add_argument("--cache-dir", default=None,
                     help="decode-once cache: a batch decoded from .xz is also written to <dir>/<batch>.cobs_classic (tmp + rename) "
                          "while it streams into HBM; later runs load that file (parallel pread, tens of GB/s) instead of "
@@ -569,9 +570,12 @@ def main(argv=None):
     # batch of this rank from the sizes table, the budget from --max-ram-gb
     from . import sizing
     from .sysinfo import effective_cpus, available_ram_gb
-    max_ram_gb = args.max_ram_gb if args.max_ram_gb > 0 else 0.8 * available_ram_gb()
-    args.loaders, budget_mb, host_mb = sizing.stage_plan([batches[p_] for p_ in mine], args.sizes, effective_cpus(), max_ram_gb,
-                                                        args.loaders)
+    # ranks of one node share its CPUs and its RAM: every rank plans with its share (LOCAL_WORLD_SIZE from the launcher;
+    # --max-ram-gb, like config.yaml's max_ram_gb, is the budget of the whole job on this node)
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world))
+    max_ram_gb = (args.max_ram_gb if args.max_ram_gb > 0 else 0.8 * available_ram_gb()) / local_world
+    args.loaders, budget_mb, host_mb = sizing.stage_plan([batches[p_] for p_ in mine], args.sizes,
+                                                        max(1, effective_cpus() // local_world), max_ram_gb, args.loaders)
     host_ram = None
     if isinstance(source, FileSource):
         host_ram = source.host_ram = sizing.HostRam(budget_mb)

@@ -488,6 +488,9 @@ def test_match_stage_plain_invocation_with_eight_ranks(pm, oracle, tmp_path):
     reports = [json.loads(ln) for ln in r.stderr.decode().splitlines() if ln.startswith("{") and '"world"' in ln]
     assert sorted(rep["rank"] for rep in reports) == list(range(8)) and all(rep["world"] == 8 for rep in reports)
     assert sorted(rep["batches"] for rep in reports) == [0, 0, 0, 1, 1, 1, 1, 1]
+    # the 8 ranks of one node share its RAM: together their xz-decoder budgets stay within what one rank alone would take
+    from phylign_amd.sysinfo import available_ram_gb
+    assert sum(rep["host_ram_plan"]["budget_mb"] for rep in reports) <= 0.8 * available_ram_gb() * 1024 * 1.1
 
 
 def test_query_chunks_do_not_accumulate_in_hbm(pm, oracle, tmp_path):

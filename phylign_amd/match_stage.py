@@ -6,6 +6,7 @@ decompress_and_run_cobs, then Snakefile:490-520 rule translate_matches).
     python -m phylign_amd.match_stage --batches data/batches_full.txt --cobs-dir cobs \
         --sizes data/decompressed_indexes_sizes.txt --queries intermediate/01_queries_merged/Q.fa \
         --out-dir intermediate/03_match [--filter-out intermediate/04_filter/Q.fa]
+    python -m phylign_amd.match_stage --input-dir input ...       # rules fix_query + concatenate_queries too: every query file of input/
     python -m phylign_amd.match_stage --gpus 8 ...                                          # starts its own 8 ranks, one per GPU
     python -m torch.distributed.run --nproc-per-node 8 ... -m phylign_amd.match_stage ...   # or under a launcher
 
@@ -430,6 +431,44 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
     return report, merge[0]
 
 
+QUERY_EXTENSIONS = ("fa", "fasta", "fq", "fastq")               # Snakefile:13
+
+
+def query_stem(path):
+    """a query file's name in the pipeline: its base name without the last suffix (Snakefile:28-29)"""
+    base = os.path.basename(path)
+    return base.rsplit(".", 1)[0] if "." in base else base
+
+
+def discover_queries(input_dir):
+    """the files of <input_dir> the reference takes as query files (Snakefile:24-29: input/*.{fa,fasta,fq,fastq})"""
+    import glob
+    return [p for ext in QUERY_EXTENSIONS for p in glob.glob(os.path.join(input_dir, f"*.{ext}"))]
+
+
+def merged_queries(pm, paths, raw, kmer_size):
+    """rules fix_query + concatenate_queries (Snakefile:314-352) for several query files: every file is prepared on its
+    own (raw: the native parser with normalise -- seqtk seq -A -U -C | awk gsub(/[^ACGT]/, "A"); else it is taken as a
+    file of intermediate/00_queries_preprocessed/), the prepared texts follow each other in the order of the sorted
+    file names, and the merged file is called after all of them joined by "___" (Snakefile:28-38).
+    Returns (name of the merged query file, its bytes)."""
+    by_stem = {}
+    for p in paths:
+        if query_stem(p) in by_stem:
+            raise SystemExit(f"two query files are called '{query_stem(p)}': {by_stem[query_stem(p)]} and {p} (Snakefile:309-311)")
+        by_stem[query_stem(p)] = p
+    texts = []
+    for stem in sorted(by_stem):
+        with open(by_stem[stem], "rb") as f:
+            data = f.read()
+        if raw:
+            q = pm.Queries(data, term_size=kmer_size, normalise=True)
+            data = q.fasta()
+            q.free()
+        texts.append(data)
+    return "___".join(sorted(by_stem)), b"".join(texts)
+
+
 def bind_rank_to_gpu(local_rank, n_visible):
     """one rank per GPU; several ranks may share a device only when the launcher narrowed the visible
     devices to one per rank (HIP_VISIBLE_DEVICES) or PHYLIGN_SHARE_GPU is set (functional tests)"""
@@ -446,7 +485,13 @@ def main(argv=None):
     ap.add_argument("--batches", default=None)
     ap.add_argument("--cobs-dir", default=None)
     ap.add_argument("--sizes", default=None, help="data/decompressed_indexes_sizes.txt")
-    ap.add_argument("--queries", required=True)
+    ap.add_argument("--queries", nargs="+", default=None,
+                    help="the merged query file (intermediate/01_queries_merged/Q.fa), or several query files: they are "
+                         "prepared one by one (with --raw-queries) and concatenated in the order of their sorted names, the "
+                         "outputs are called after all of them joined by ___ (rules fix_query + concatenate_queries)")
+    ap.add_argument("--input-dir", default=None,
+                    help="instead of --queries: every *.fa / *.fasta / *.fq / *.fastq of this directory (the reference's "
+                         "input/, Snakefile:24-29); implies --raw-queries")
     ap.add_argument("--out-dir", required=True)
     ap.add_argument("--threshold", type=float, default=0.7)          # config.yaml:20
     ap.add_argument("--nb-best-hits", type=int, default=100)         # config.yaml:23
@@ -489,6 +534,8 @@ def main(argv=None):
                          "says, or one)")
     args = ap.parse_args(argv)
     from . import launch
+    if not args.queries and not args.input_dir:
+        ap.error("--queries or --input-dir is required")
     if launch.wants_self_launch(args.gpus):
         # this process has not touched the GPU: start the ranks as children, relay their status
         sys.exit(launch.self_launch_module("phylign_amd.match_stage", sys.argv[1:] if argv is None else argv, args.gpus))
@@ -539,20 +586,30 @@ def main(argv=None):
         source = FileSource(pm, args.cobs_dir, sizes, cache_dir=cache_dir)
     parts = W.assign_named(batches, sizes, world)
     mine = parts[rank]
-    qfile = os.path.basename(args.queries)
-    qfile = qfile[:-3] if qfile.endswith(".fa") else qfile
-    with open(args.queries, "rb") as f:
-        fasta = f.read()
-    # a query file with more reads than --query-chunk is searched in pieces: the chunks share the resident batches of a
-    # group, every batch's file grows by one piece per chunk, and the 04_filter FASTA is emitted chunk after chunk
-    if args.raw_queries:
-        prepared = pm.Queries(fasta, term_size=args.kmer_size, normalise=True)
-        if prepared.count()[0] > args.query_chunk > 0:
-            fasta = prepared.fasta()                               # the prepared single-line form can be cut at '>' lines
-            prepared.free()
-            prepared = None
+    if args.input_dir:
+        qpaths = discover_queries(args.input_dir)
+        args.raw_queries = True
+        if not qpaths:
+            ap.error(f"no query file (*.fa, *.fasta, *.fq, *.fastq) in {args.input_dir}")
     else:
-        prepared = None
+        qpaths = list(args.queries)
+    prepared = None
+    if len(qpaths) > 1 or args.input_dir:
+        # rules fix_query + concatenate_queries: the merged, prepared file is built here and searched like one
+        qfile, fasta = merged_queries(pm, qpaths, args.raw_queries, args.kmer_size)
+    else:
+        qfile = os.path.basename(qpaths[0])
+        qfile = qfile[:-3] if qfile.endswith(".fa") else qfile
+        with open(qpaths[0], "rb") as f:
+            fasta = f.read()
+        # a query file with more reads than --query-chunk is searched in pieces: the chunks share the resident batches of a
+        # group, every batch's file grows by one piece per chunk, and the 04_filter FASTA is emitted chunk after chunk
+        if args.raw_queries:
+            prepared = pm.Queries(fasta, term_size=args.kmer_size, normalise=True)
+            if prepared.count()[0] > args.query_chunk > 0:
+                fasta = prepared.fasta()                               # the prepared single-line form can be cut at '>' lines
+                prepared.free()
+                prepared = None
     pieces = [fasta] if prepared is not None else split_prepared_fasta(fasta, args.query_chunk, args.query_piece_mb << 20)
     parser = ThreadPoolExecutor(max_workers=1)
     if prepared is not None:

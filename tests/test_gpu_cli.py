@@ -272,6 +272,42 @@ def test_match_stage_takes_unprepared_queries(pm, oracle, tmp_path):
         assert gzip.open(tmp_path / "03_match" / f"{b}____raw.gz", "rt").read() == exp, b
 
 
+def test_match_stage_takes_the_reference_input_directory(pm, oracle, tmp_path):
+    """--input-dir: rules fix_query + concatenate_queries (Snakefile:314-352) for the reference's own four bundled query
+    files (FASTQ and FASTA, tests/golden/reads/raw/): each is prepared by the native parser, the prepared texts follow
+    each other in the order of the sorted names, and every output is called after reads_1___reads_2___reads_3___reads_4
+    (Snakefile:28-38) -- the same bytes as for the merged file the reference's pipeline made of them (tests/golden/reads/),
+    and as for the four files given one by one in another order"""
+    names, indexes, _ = _stage_fixture(oracle, tmp_path, n_batches=2)
+    gold = os.path.join(ROOT, "tests", "golden", "reads")
+    merged_name = "reads_1___reads_2___reads_3___reads_4"
+    merged = open(os.path.join(gold, merged_name + ".fa"), "rb").read()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+            "--cobs-dir", str(tmp_path / "cobs"), "--sizes", str(tmp_path / "sizes.txt"), "--nb-best-hits", "3"]
+    raw = [os.path.join(gold, "raw", f) for f in ("reads_3.fasta", "reads_1.fastq", "reads_4.fa", "reads_2.fq")]
+    runs = {"dir": ["--input-dir", os.path.join(gold, "raw")], "files": ["--raw-queries", "--queries"] + raw,
+            "merged": ["--queries", os.path.join(gold, merged_name + ".fa")]}
+    for tag, extra in runs.items():
+        r = subprocess.run(base + extra + ["--out-dir", str(tmp_path / f"03_{tag}"), "--filter-out", str(tmp_path / f"04_{tag}" / "out.fa")],
+                           capture_output=True, env=env)
+        assert r.returncode == 0, (tag, r.stderr.decode()[-2000:])
+    from phylign_amd import postprocess as P
+    for b in names:
+        exp = P.filter_text(oracle.query_file(indexes[b], merged, 0.7).decode(), 3)
+        assert exp.count("*") == 40
+        for tag in runs:
+            assert gzip.open(tmp_path / f"03_{tag}" / f"{b}____{merged_name}.gz", "rt").read() == exp, (b, tag)
+    fa = {tag: (tmp_path / f"04_{tag}" / "out.fa").read_bytes() for tag in runs}
+    assert fa["dir"] == fa["files"] == fa["merged"] and fa["dir"].count(b">") == 40
+    # two files with one name are refused like the reference's get_query_file asserts (Snakefile:309-311)
+    (tmp_path / "in2").mkdir()
+    for ext in ("fa", "fq"):
+        (tmp_path / "in2" / f"same.{ext}").write_bytes(open(raw[0], "rb").read())
+    r = subprocess.run(base + ["--input-dir", str(tmp_path / "in2"), "--out-dir", str(tmp_path / "03_x")], capture_output=True, env=env)
+    assert r.returncode != 0 and b"two query files" in r.stderr
+
+
 def test_match_stage_fails_fast_on_a_broken_index(pm, oracle, tmp_path):
     """a truncated index stream in the middle of the batch list, loaders queued behind a tiny HBM
     budget: the stage exits non-zero promptly (waiting loaders are told to give up) and leaves no

@@ -469,6 +469,48 @@ def merged_queries(pm, paths, raw, kmer_size):
     return "___".join(sorted(by_stem)), b"".join(texts)
 
 
+def apply_reference_config(args, ap):
+    """--config: the stage takes its parameters from the reference's own config.yaml and directory layout, i.e. it is the
+    reference's `match` target (Snakefile:249-253) run from the pipeline's directory (--workdir, default: the directory of
+    the config file).  Command-line flags given explicitly win.  Keys read: batches, cobs_kmer_thres, nb_best_hits,
+    download_dir, index_load_mode, decompression_dir, keep_cobs_indexes, max_ram_gb (config.yaml; Snakefile:126-175)."""
+    import yaml
+    with open(args.config) as f:
+        cfg = yaml.safe_load(f) or {}
+    wd = args.workdir or os.path.dirname(os.path.abspath(args.config))
+
+    def in_wd(p_):
+        return p_ if os.path.isabs(p_) else os.path.join(wd, p_)
+    mode = str(cfg.get("index_load_mode", "mem-stream"))
+    if mode not in ("mem-stream", "mem-disk", "mmap-disk"):
+        ap.error(f"config: index_load_mode must be one of mem-stream, mem-disk, mmap-disk (Snakefile:124-131), not {mode!r}")
+    given = set(args.given)
+    if "batches" not in given:
+        args.batches = in_wd(str(cfg["batches"]))                                        # Snakefile:32-34
+    if "cobs_dir" not in given:
+        args.cobs_dir = in_wd(os.path.join(str(cfg.get("download_dir", ".")), "cobs"))  # Snakefile:151
+    if "sizes" not in given:
+        args.sizes = in_wd("data/decompressed_indexes_sizes.txt")                        # Snakefile:373
+    if "threshold" not in given:
+        args.threshold = float(cfg.get("cobs_kmer_thres", args.threshold))               # Snakefile:410
+    if "nb_best_hits" not in given:
+        args.nb_best_hits = int(cfg.get("nb_best_hits", args.nb_best_hits))              # Snakefile:412
+    if "max_ram_gb" not in given and "max_ram_gb" in cfg:
+        args.max_ram_gb = float(cfg["max_ram_gb"])                                       # Snakefile:109
+    if "index_load_mode" not in given:
+        args.index_load_mode = mode
+    if "decompression_dir" not in given:
+        args.decompression_dir = in_wd(str(cfg.get("decompression_dir", "intermediate/02_cobs_decompressed")))   # Snakefile:152-154
+    # mem-stream never decompresses to disk; in the disk modes a decompressed index is temp() unless keep_cobs_indexes
+    # (Snakefile:155-175, :366-370): without it nothing needs to be written at all, the matrix goes straight to HBM
+    args.keep_cobs_indexes = bool(cfg.get("keep_cobs_indexes", False)) and args.index_load_mode != "mem-stream"
+    if "queries" not in given and "input_dir" not in given:
+        args.input_dir = in_wd("input")                                                  # Snakefile:24-25
+    if "out_dir" not in given:
+        args.out_dir = in_wd("intermediate/03_match")                                    # Snakefile:394
+    args.filter_dir = in_wd("intermediate/04_filter")                                    # Snakefile:497 (named after the merged query file)
+
+
 def bind_rank_to_gpu(local_rank, n_visible):
     """one rank per GPU; several ranks may share a device only when the launcher narrowed the visible
     devices to one per rank (HIP_VISIBLE_DEVICES) or PHYLIGN_SHARE_GPU is set (functional tests)"""
@@ -492,7 +534,13 @@ def main(argv=None):
     ap.add_argument("--input-dir", default=None,
                     help="instead of --queries: every *.fa / *.fasta / *.fq / *.fastq of this directory (the reference's "
                          "input/, Snakefile:24-29); implies --raw-queries")
-    ap.add_argument("--out-dir", required=True)
+    ap.add_argument("--out-dir", default=None)
+    ap.add_argument("--config", default=None,
+                    help="the reference's config.yaml: batches, cobs_kmer_thres, nb_best_hits, download_dir, index_load_mode, "
+                         "decompression_dir, keep_cobs_indexes and max_ram_gb are taken from it, queries from input/, outputs go to "
+                         "intermediate/03_match and intermediate/04_filter/<merged name>.fa -- the reference's `match` target "
+                         "(Snakefile:249-253).  Flags given on the command line win")
+    ap.add_argument("--workdir", default=None, help="with --config: the pipeline's directory (default: where the config file is)")
     ap.add_argument("--threshold", type=float, default=0.7)          # config.yaml:20
     ap.add_argument("--nb-best-hits", type=int, default=100)         # config.yaml:23
     ap.add_argument("--filter-out", default=None)
@@ -533,6 +581,14 @@ def main(argv=None):
                          "`python -m phylign_amd.match_stage --gpus 8 ...` starts 8 fresh ranks of itself (0 = what the launcher "
                          "says, or one)")
     args = ap.parse_args(argv)
+    # which options the command line really set (so that --config only fills in the others)
+    argv_seen = sys.argv[1:] if argv is None else list(argv)
+    args.given = {a.dest for a in ap._actions if any(tok == o or tok.startswith(o + "=") for o in a.option_strings for tok in argv_seen)}
+    args.keep_cobs_indexes, args.filter_dir = True, None
+    if args.config:
+        apply_reference_config(args, ap)
+    if not args.out_dir:
+        ap.error("--out-dir is required (or --config)")
     from . import launch
     if not args.queries and not args.input_dir:
         ap.error("--queries or --input-dir is required")
@@ -579,7 +635,7 @@ def main(argv=None):
         batches = read_batches(args.batches)
         sizes = read_sizes(args.sizes)
         cache_dir = args.cache_dir
-        if args.index_load_mode != "mem-stream":
+        if args.index_load_mode != "mem-stream" and (args.keep_cobs_indexes or not args.config):
             cache_dir = cache_dir or args.decompression_dir
             if not cache_dir:
                 ap.error("--index-load-mode mem-disk needs --decompression-dir (or --cache-dir)")
@@ -610,6 +666,8 @@ def main(argv=None):
                 fasta = prepared.fasta()                               # the prepared single-line form can be cut at '>' lines
                 prepared.free()
                 prepared = None
+    if args.filter_dir and not args.filter_out:
+        args.filter_out = os.path.join(args.filter_dir, f"{qfile}.fa")
     pieces = [fasta] if prepared is not None else split_prepared_fasta(fasta, args.query_chunk, args.query_piece_mb << 20)
     parser = ThreadPoolExecutor(max_workers=1)
     if prepared is not None:

@@ -308,6 +308,49 @@ def test_match_stage_takes_the_reference_input_directory(pm, oracle, tmp_path):
     assert r.returncode != 0 and b"two query files" in r.stderr
 
 
+def test_match_stage_runs_the_match_target_from_the_reference_config(pm, oracle, tmp_path):
+    """--config: a directory laid out like the reference's (config.yaml with its keys, data/, cobs/, input/) and ONE
+    command in place of `snakemake match` (Snakefile:249-253): queries from input/, batches / threshold / nb_best_hits /
+    load mode from the config, outputs in intermediate/03_match and intermediate/04_filter/<merged name>.fa; mem-disk with
+    keep_cobs_indexes leaves the decompressed indexes in intermediate/02_cobs_decompressed, mem-stream leaves none"""
+    import shutil
+    names, indexes, _ = _stage_fixture(oracle, tmp_path, n_batches=2)
+    gold = os.path.join(ROOT, "tests", "golden", "reads")
+    merged_name = "reads_1___reads_2___reads_3___reads_4"
+    merged = open(os.path.join(gold, merged_name + ".fa"), "rb").read()
+    from phylign_amd import postprocess as P
+    for mode, keep in (("mem-disk", True), ("mem-stream", True), ("mem-disk", False)):
+        wd = tmp_path / f"phylign_{mode}_{keep}"
+        (wd / "data").mkdir(parents=True)
+        shutil.copytree(tmp_path / "cobs", wd / "cobs")
+        shutil.copytree(os.path.join(gold, "raw"), wd / "input")
+        shutil.copy(tmp_path / "batches.txt", wd / "data" / "batches_small.txt")
+        shutil.copy(tmp_path / "sizes.txt", wd / "data" / "decompressed_indexes_sizes.txt")
+        (wd / "config.yaml").write_text(
+            "batches: \"data/batches_small.txt\"\ncobs_kmer_thres: 0.7\nnb_best_hits: 3\nminimap_preset: \"sr\"\nthreads: all\n"
+            f"max_ram_gb: 12\ndownload_dir: \".\"\ncobs_threads: auto\nindex_load_mode: {mode}\nkeep_cobs_indexes: {keep}\n")
+        r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--config", str(wd / "config.yaml")],
+                           capture_output=True, env=dict(os.environ, PYTHONPATH=ROOT), cwd=str(tmp_path))
+        assert r.returncode == 0, (mode, r.stderr.decode()[-2000:])
+        for b in names:
+            exp = P.filter_text(oracle.query_file(indexes[b], merged, 0.7).decode(), 3)
+            assert gzip.open(wd / "intermediate" / "03_match" / f"{b}____{merged_name}.gz", "rt").read() == exp, (b, mode)
+        fa = (wd / "intermediate" / "04_filter" / f"{merged_name}.fa").read_bytes()
+        assert fa.count(b">") == 40
+        kept = sorted(p_.name for p_ in (wd / "intermediate" / "02_cobs_decompressed").glob("*.cobs_classic")) \
+            if (wd / "intermediate" / "02_cobs_decompressed").exists() else []
+        assert kept == ([f"{b}.cobs_classic" for b in sorted(names)] if (mode == "mem-disk" and keep) else []), (mode, keep, kept)
+        if kept:
+            assert all((wd / "intermediate" / "02_cobs_decompressed" / f"{b}.cobs_classic").read_bytes() == bytes(indexes[b]) for b in names)
+    # a flag on the command line wins over the config
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--config", str(wd / "config.yaml"), "--nb-best-hits", "1",
+                        "--out-dir", str(tmp_path / "03_flag")], capture_output=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    b = names[0]
+    assert gzip.open(tmp_path / "03_flag" / f"{b}____{merged_name}.gz", "rt").read() == \
+        P.filter_text(oracle.query_file(indexes[b], merged, 0.7).decode(), 1)
+
+
 def test_match_stage_fails_fast_on_a_broken_index(pm, oracle, tmp_path):
     """a truncated index stream in the middle of the batch list, loaders queued behind a tiny HBM
     budget: the stage exits non-zero promptly (waiting loaders are told to give up) and leaves no

@@ -1405,3 +1405,33 @@ def test_oracle_equals_the_independent_python_restatement(oracle, threshold):
         h = oracle.header_parse(index)
         assert (h.term_size, h.n_docs, h.signature_size, h.num_hashes) == (k, D, S, num_hashes)
         assert oracle.query_file(index, fasta, threshold) == I.query_text(records, names, m, k, num_hashes, S, threshold, canon), case
+
+
+def test_oracle_equals_the_independent_restatement_on_random_small_cases(oracle):
+    """the same comparison over 60 random shapes: k = 4 ... 71, 1 - 3 hash functions, canonical or not, 1 ... 200 documents,
+    reads of k ... k + 40 bases, thresholds 0 ... 1 -- whole texts"""
+    pytest.importorskip("xxhash")
+    import independent as I
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        k = int(rng.choice([4, 5, 8, 15, 16, 21, 31, 32, 33, 47, 64, 71]))
+        nh, canon, D = int(rng.integers(1, 4)), bool(rng.integers(0, 2)), int(rng.integers(1, 201))
+        glen = int(rng.integers(k + 5, 400))
+        genomes = ["".join("ACGT"[c] for c in rng.integers(0, 4, size=glen)) for _ in range(min(D, 12))]
+        genomes = [genomes[d % len(genomes)] for d in range(D)]                 # documents repeat: equal scores, tie groups
+        names = [f"{d:04x}_doc{d}" for d in range(D)]
+        S = int(rng.integers(7, 4 * glen))
+        index, m = I.classic_index(names, genomes, k, nh, S, canon)
+        records = []
+        for i in range(6):
+            g = genomes[int(rng.integers(0, len(genomes)))]
+            L = int(rng.integers(k, min(k + 41, glen) + 1))
+            p = int(rng.integers(0, glen - L + 1))
+            s = list(g[p:p + L])
+            for j in range(L):
+                if rng.random() < 0.05 * (i % 3):
+                    s[j] = "ACGT"[int(rng.integers(0, 4))]
+            records.append((f"r{i} len={L}", "".join(s)))
+        fasta = "".join(f">{h}\n{s}\n" for h, s in records).encode()
+        thr = float(rng.choice([0.0, 0.2, 0.5, 0.7, 0.9, 1.0]))
+        assert oracle.query_file(index, fasta, thr) == I.query_text(records, names, m, k, nh, S, thr, canon), (it, k, nh, canon, D, S, thr)

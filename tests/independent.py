@@ -102,3 +102,60 @@ def built_case(*case):
     index, m = classic_index(names, genomes, k, num_hashes, S, canon)
     fasta = "".join(f">{h}\n{s}\n" for h, s in records).encode()
     return index, m, fasta, names, S, records
+
+
+# ---- the compact index (SURVEY.md 8f rank 3): sub-indexes of page_size x 8 documents, each with its own signature size
+# and number of hash functions; one header, the closing magic ends on a page boundary, sub-matrices follow page-wide ----
+def compact_index(names, genomes, k, page, params, canon=True):
+    """.cobs_compact bytes and the sub-matrices; params = [(signature_size, num_hashes)] per sub-index"""
+    D, per = len(names), page * 8
+    assert (D + per - 1) // per == len(params)
+    mats = []
+    for p_, (S, nh) in enumerate(params):
+        m = np.zeros((S, page), dtype=np.uint8)
+        for d in range(p_ * per, min(D, (p_ + 1) * per)):
+            dl = d - p_ * per
+            for rr in rows_of(genomes[d], k, nh, S, canon):
+                for r in rr:
+                    m[r, dl >> 3] |= 1 << (dl & 7)
+        mats.append(m)
+    head = b"COBS:" + b"COMPACT_INDEX" + struct.pack("<IIBIIQ", 1, k, 1 if canon else 0, len(params), D, page)
+    head += b"".join(struct.pack("<QQ", S, nh) for S, nh in params)
+    head += b"".join(n.encode() + b"\n" for n in names)
+    head += bytes((page - (len(head) + 13) % page) % page) + b"COMPACT_INDEX"
+    assert len(head) % page == 0
+    return head + b"".join(m.tobytes() for m in mats), mats
+
+
+def query_text_compact(records, names, mats, k, page, params, threshold, canon=True):
+    out = []
+    D, per = len(names), page * 8
+    for header, seq in records:
+        score = [0] * D
+        n_kmers = len(seq) - k + 1
+        for p_, (S, nh) in enumerate(params):
+            lo, hi = p_ * per, min(D, (p_ + 1) * per)
+            for rr in rows_of(seq, k, nh, S, canon):
+                acc = None
+                for r in rr:
+                    bits = np.unpackbits(mats[p_][r], bitorder="little")[:hi - lo]
+                    acc = bits if acc is None else (acc & bits)
+                for dl in np.nonzero(acc)[0]:
+                    score[lo + int(dl)] += 1
+        need = math.ceil(threshold * n_kmers)
+        hits = sorted((d for d in range(D) if score[d] >= need), key=lambda d: (-score[d], d))
+        out.append(f"*{header}\t{len(hits)}\n" + "".join(f"{names[d]}\t{score[d]}\n" for d in hits))
+    return "".join(out).encode()
+
+
+COMPACT_CASES = [(11, 8, 150, [(900, 1), (700, 2), (1100, 1)], 31), (12, 16, 300, [(500, 1), (800, 1), (300, 3)], 31),
+                 (13, 32, 40, [(2000, 2)], 21)]
+
+
+@functools.lru_cache(maxsize=None)
+def built_compact_case(seed, page, D, params, k):
+    """(index bytes, sub-matrices, fasta, names, records) of one of COMPACT_CASES (params as a tuple of pairs)"""
+    names, genomes, _S, records = make_case(seed, D, 700, k, 1, True)
+    index, mats = compact_index(names, genomes, k, page, list(params), True)
+    fasta = "".join(f">{h}\n{s}\n" for h, s in records).encode()
+    return index, mats, fasta, names, records

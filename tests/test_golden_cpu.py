@@ -1435,3 +1435,17 @@ def test_oracle_equals_the_independent_restatement_on_random_small_cases(oracle)
         fasta = "".join(f">{h}\n{s}\n" for h, s in records).encode()
         thr = float(rng.choice([0.0, 0.2, 0.5, 0.7, 0.9, 1.0]))
         assert oracle.query_file(index, fasta, thr) == I.query_text(records, names, m, k, nh, S, thr, canon), (it, k, nh, canon, D, S, thr)
+
+
+@pytest.mark.parametrize("threshold", [0.7, 0.0, 0.4])
+def test_oracle_equals_the_independent_restatement_on_compact_indexes(oracle, threshold):
+    """.cobs_compact written and scored by tests/independent.py: header with per-sub-index
+    (signature_size, num_hashes), padding to the page boundary, page-wide sub-matrices; the oracle reads the file and
+    prints the same text (documents of the last sub-index partly filled, sub-indexes with 1 - 3 hash functions)"""
+    pytest.importorskip("xxhash")
+    import independent as I
+    for seed, page, D, params, k in I.COMPACT_CASES:
+        index, mats, fasta, names, records = I.built_compact_case(seed, page, D, tuple(params), k)
+        c = oracle.compact_parse(index)
+        assert (c.n_docs, c.page_size) == (D, page)
+        assert oracle.query_file(index, fasta, threshold) == I.query_text_compact(records, names, mats, k, page, params, threshold), (seed, threshold)

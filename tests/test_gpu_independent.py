@@ -24,3 +24,19 @@ def test_product_equals_an_independent_python_restatement(pm, case, threshold):
         assert pm.query_text(ix, fasta, threshold) == want, (seed, threshold, bound)
     pm.set_option("threshold_bound", 1)
     ix.free()
+
+
+@pytest.mark.parametrize("case", I.COMPACT_CASES)
+@pytest.mark.parametrize("threshold", [0.7, 0.0, 0.4])
+def test_product_equals_the_independent_restatement_on_compact_indexes(pm, case, threshold):
+    seed, page, D, params, k = case
+    index, mats, fasta, names, records = I.built_compact_case(seed, page, D, tuple(params), k)
+    want = I.query_text_compact(records, names, mats, k, page, params, threshold)
+    for layout in (1, 2):
+        ix = pm.Index.load_mem(index, layout=layout)
+        assert (ix.info.n_parts, ix.info.page_size, ix.info.n_docs) == (len(params), page, D)
+        for bound in (1, 0):
+            pm.set_option("threshold_bound", bound)
+            assert pm.query_text(ix, fasta, threshold) == want, (seed, threshold, layout, bound)
+        pm.set_option("threshold_bound", 1)
+        ix.free()

@@ -175,7 +175,9 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="steps queued ahead of the one the host is finishing (0 = 1 on one GPU, 2 with N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-target-s", type=float, default=24.0, help="timed CPU work of the baseline (2 partitions x 3 runs)")
+    ap.add_argument("--cpu-target-s", type=float, default=16.0,
+                    help="sizes the CPU baseline's query sample: 6 runs (2 partitions x 3) of about target / 6 s each by the faster "
+                         "partition; the column-slab partition runs ~2.5 x longer, so 16 gives about 25 s of timed CPU work")
     ap.add_argument("--cpu-sample-gb", type=float, default=0.0,
                     help="host-RAM size of the CPU baseline's index sample (0 = min(48 GB, 35 %% of the RAM available to the job))")
     ap.add_argument("--dump-hits", default=None, help="rank 0 saves the ordered hit records of the headline mode (.npy)")

@@ -486,6 +486,8 @@ def apply_reference_config(args, ap):
         ap.error(f"config: index_load_mode must be one of mem-stream, mem-disk, mmap-disk (Snakefile:124-131), not {mode!r}")
     given = set(args.given)
     if "batches" not in given:
+        if "batches" not in cfg:
+            ap.error(f"{args.config}: no `batches` key (config.yaml:9; or give --batches)")
         args.batches = in_wd(str(cfg["batches"]))                                        # Snakefile:32-34
     if "cobs_dir" not in given:
         args.cobs_dir = in_wd(os.path.join(str(cfg.get("download_dir", ".")), "cobs"))  # Snakefile:151

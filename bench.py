@@ -160,6 +160,10 @@ def main():
                     help="skip the other scan mode, the clustered variant and the fetched-bytes pass (profiling runs)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered (home batch) variant")
     ap.add_argument("--no-l31", action="store_true", help="skip the 31-bp (one k-mer per query) legs")
+    ap.add_argument("--no-argannot", action="store_true",
+                    help="skip the gene-length leg (SURVEY.md 8d: the length mix of the reference's data/ARGannot_r3.fa)")
+    ap.add_argument("--no-unique-rows", action="store_true",
+                    help="skip the untimed pass that counts the distinct signature rows the query set touches (SURVEY.md 8d)")
     ap.add_argument("--no-full-shard", action="store_true",
                     help="skip the configs[3]/[4] leg (one rank's shard of the full 305-batch collection, generated after the headline set is freed)")
     ap.add_argument("--full-shard-world", type=int, default=8)
@@ -196,6 +200,7 @@ def main():
         # plain `python bench.py --gpus N`: this process has not touched the GPU (torch is not even imported yet), so it
         # starts N fresh ranks of the same command line, relays their output (rank 0 prints the JSON line) and their status
         sys.exit(launch.self_launch_script(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    launch.arm_parent_death_signal()          # a rank of that launcher: ends with it
     if world != args.gpus:
         args.gpus = world
 
@@ -291,6 +296,9 @@ def main():
     log(f"[bench] rank0: {len(indexes)} batches, {resident / 1e9:.1f} GB of signatures resident, "
         f"{nq} queries / {n_terms} k-mers, setup {time.time() - t0:.1f}s")
 
+    def rendezvous_store():
+        return dist.distributed_c10d._get_default_store()
+
     def sync():
         torch.cuda.synchronize()
         if multi:
@@ -307,15 +315,17 @@ def main():
     phase = {"queue": 0.0, "wait": 0.0, "host": 0.0, "gather": 0.0}
 
     def narrow_lines(infs, shares=None):
-        """128-byte lines one k-mer touches in the batches of the mixed-width launch (rows of at most 256 bytes); a batch
-        searched with a share of the queries counts by that share"""
+        """128-byte lines one k-mer touches in the batches of the mixed-width launch (rows of at most 256 bytes) per
+        algorithmic byte of those rows; a batch searched with a share of the queries counts by that share"""
         w = [1.0 if sh is None else (sh[1] - sh[0]) / sh[2] for sh in (shares or [None] * len(infs))]
-        return sum(max(1, int(i.stride) // 128) * w_ for i, w_ in zip(infs, w) if i.stride <= 256)
+        lines = sum(max(1, int(i.stride) // 128) * w_ for i, w_ in zip(infs, w) if i.stride <= 256)
+        rowb = sum(int(i.row_bytes) * w_ for i, w_ in zip(infs, w) if i.stride <= 256)
+        return lines / rowb if rowb else 0.0
 
     # what the step functions below run on; swapped for the l31 and full_shard legs
     cur = {"indexes": indexes, "q": q, "n_terms": n_terms, "rowsum": sum(s.row_bytes for s in shapes),
            "slot_base": bases[part_id], "terms_per_q": terms_per_q, "tag": args.workload,
-           "narrow_lines_per_kmer": narrow_lines(infos, my_shares), "shares": my_shares}
+           "narrow_lines_per_byte": narrow_lines(infos, my_shares), "shares": my_shares}
 
     def queue_step():
         t_a = time.perf_counter()
@@ -439,11 +449,16 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("pm_kernels_blob") != blob:
                 return None, f"profiles/pmc_traffic.json was measured on pm_kernels.hip blob {str(tj.get('pm_kernels_blob'))[:12]}, this is {blob[:12]}: re-run tools/run_pmc.sh"
-            if tj.get("workload") == cur["tag"] and tj.get("queries") == args.queries and world == 1 and args.rows_divisor == 1 \
+            if world > 1 or args.emulate_world:
+                return None, (f"the PMC passes (profiles/pmc_traffic.json) were collected on the 1-rank launch that covers all "
+                              f"{len(shapes)} batches; a rank of {nparts} launches over its own shard only, so the per-launch figure "
+                              "does not transfer (1-rank ratio traffic / algorithmic: see the N = 1 line)")
+            if tj.get("workload") == cur["tag"] and tj.get("queries") == args.queries and args.rows_divisor == 1 \
                     and args.qlen == tj.get("query_len", 150):
                 ent = tj.get("kernels", {}).get(name, {}).get(mode)
                 if ent:
                     return ent.get("hbm_bytes_per_launch"), None
+            return None, "no PMC pass committed for this workload / query count / row divisor (tools/run_pmc.sh)"
         except Exception:
             pass
         return None, None
@@ -497,7 +512,7 @@ def main():
         r = roofline_entry(groups, name, steps, mode, fetched)
         abytes, ms, launches, nb, nqk = groups[name]
         if mode == "fetch_all_rows":
-            lines = cur["narrow_lines_per_kmer"] * nqk * cur["terms_per_q"]       # 128-byte lines touched per launch
+            lines = cur["narrow_lines_per_byte"] * abytes / launches              # 128-byte lines touched per launch
             r["lines_per_s"] = lines / (ms / launches * 1e-3)
             r["wire_GBps_at_128B_per_line"] = lines * 128 / (ms / launches * 1e-3) / 1e9
             r["wire_frac_of_peak"] = r["wire_GBps_at_128B_per_line"] / HBM_PEAK_GBPS
@@ -563,6 +578,78 @@ def main():
         sum_other["hits_identical_to_headline"] = same
         sum_other["speed_vs_headline"] = sum_other["value"] / sum_head["value"]
         ok = ok and same
+
+    # ---- SURVEY.md 8d, many-queries regime: "report additionally unique_rows x row_bytes and label it".  One untimed
+    # device pass per resident batch marks the rows the 12 M k-mers map to in a bitmap of signature_size bits.
+    unique_rows = None
+    if (full or multi) and not args.no_unique_rows and not args.only_headline and not args.emulate_world:
+        from phylign_amd import bench_aids
+        t0 = time.time()
+        mine_rows = mine_bytes = mine_alg = 0
+        for ix, inf in zip(indexes, infos):
+            u = bench_aids.unique_rows(ix, q)
+            mine_rows += u; mine_bytes += u * int(inf.row_bytes); mine_alg += n_terms * int(inf.num_hashes) * int(inf.row_bytes)
+        tot = [mine_rows, mine_bytes, mine_alg, sum(int(i.signature_size) for i in infos), sum(int(i.signature_size) * int(i.row_bytes) for i in infos)]
+        if multi:
+            t = torch.tensor(tot, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            tot = [int(v) for v in t.tolist()]
+        unique_rows = {"label": "unique_rows x row_bytes (SURVEY.md 8d, many-queries regime): the distinct signature rows the query set's "
+                                "k-mers map to, summed over the resident batches -- what a scan with perfect row reuse would read; "
+                                "NOT what `value`, `roofline` or the algorithmic bytes are priced at",
+                       "unique_rows": tot[0], "unique_rows_x_row_bytes": tot[1], "algorithmic_bytes_per_step": tot[2],
+                       "ratio_to_algorithmic": tot[1] / tot[2] if tot[2] else None,
+                       "rows_resident": tot[3], "fraction_of_resident_rows_touched": tot[0] / tot[3] if tot[3] else None,
+                       "fraction_of_resident_matrix_bytes": tot[1] / tot[4] if tot[4] else None,
+                       "pass_s": round(time.time() - t0, 3)}
+
+    # ---- SURVEY.md 8d's third query shape: the reference's bundled gene file data/ARGannot_r3.fa -- 1 856 genes of
+    # 237 ... 3 153 bp (1 594 532 31-mers) in file order, uniform ACGT of those lengths.  Every gene falls into the 10- or
+    # the 13-plane counter class (128 ... 1 023 / 1 024 ... 8 191 k-mers); the file as it is (x1) and eight files' worth
+    # (x8: 12.8 M k-mers, the headline's volume) against the resident set, both scan modes, records compared.
+    argannot = None
+    if full and not args.no_argannot and world == 1:
+        saved = dict(cur)
+        try:
+            lens = W.argannot_lengths()
+            argannot = {"workload": f"length mix of data/ARGannot_r3.fa ({len(lens)} genes, {min(lens)}-{max(lens)} bp, "
+                                    f"{sum(n - 30 for n in lens)} 31-mers per file) against the {len(indexes)} resident batches"}
+            for rep in (1, 8):
+                terms = [n - 30 for n in lens] * rep
+                fa_g, _ = W.make_queries_lengths(lens * rep, seed=41 + rep, prefix="gene")
+                qg = pm.Queries(fa_g, term_size=31)
+                nqg, ntg = qg.count()
+                plan_g, sure_g = W.plant_plan_ragged(qg.hash_terms(1, 1), terms, shapes, every=16, threshold=args.threshold)
+                for pos, ix in zip(mine, indexes):
+                    if pos in plan_g:
+                        ix.plant(*plan_g[pos])
+                cur.update({"q": qg, "n_terms": ntg, "terms_per_q": None, "tag": f"{args.workload}/argannot_x{rep}"})
+                g_steps = max(3, min(args.steps, 10))
+                ent = {"queries": nqg, "kmers": ntg, "planted_pairs_at_or_above_threshold": sure_g}
+                g_runs = {}
+                for m in modes:
+                    r = timed_run(m == "threshold_bound", 2, g_steps)
+                    fp = fetched_pass(m == "threshold_bound")
+                    if m == "fetch_all_rows":
+                        for k_, (f_, a_) in fp.items():
+                            assert f_ == a_, f"{k_}: fetch-all scan gathered {f_} bytes, algorithmic bytes are {a_}"
+                    g_runs[m] = r
+                    sm = summary(r, g_steps, m, fp)
+                    sm["scan_launches"] = {k_: {"launches_per_step": v[2] / g_steps, "batches": v[3], "queries": v[4], "avg_ms": v[1] / v[2],
+                                                "algorithmic_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k_, v in r["groups"].items()}
+                    ent[m] = sm
+                same = bool(np.array_equal(g_runs[modes[0]]["hits"], g_runs[modes[1]]["hits"]))
+                n_real = int(np.count_nonzero(g_runs[modes[0]]["hits"]["doc"] != pm.PM_DOC_COUNT))
+                ent["hits_identical"] = same
+                ok = ok and same and n_real >= sure_g
+                argannot[f"x{rep}"] = ent
+                cur.clear(); cur.update(saved)
+                qg.free()
+        except Exception as e:                                       # an optional leg never costs the headline line
+            log(f"[bench] argannot leg failed: {e!r}")
+            argannot = dict(argannot or {}, error=repr(e))
+            cur.clear(); cur.update(saved)
+        pm.set_option("threshold_bound", 1)
 
     # ---- clustered variant: every query gets a home batch (changes the resident matrices: last)
     clustered = None
@@ -639,7 +726,7 @@ def main():
                 f"{sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
             saved = dict(cur)
             cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fshapes), "slot_base": fbases[rank],
-                        "tag": f"full/{world}", "narrow_lines_per_kmer": narrow_lines(finfos), "shares": None})
+                        "tag": f"full/{world}", "narrow_lines_per_byte": narrow_lines(finfos), "shares": None})
             fc_steps = max(3, min(args.steps, 10))
             full_collection = {"workload": f"all {len(fshapes)} batches of batches_full.txt ({sum(sh.index_bytes for sh in fshapes) / 1e12:.2f} TB of "
                                            f"signatures, {cur['rowsum']} row bytes per k-mer) sharded over {world} ranks, {nq} x {args.qlen} bp queries, "
@@ -741,7 +828,7 @@ def main():
             log(f"[bench] full_shard: {len(indexes)} batches, {sum(i.device_bytes for i in finfos) / 1e9:.1f} GB resident, setup {time.time() - t0:.1f}s")
             saved = dict(cur)
             cur.update({"indexes": indexes, "rowsum": sum(sh.row_bytes for sh in fsub), "slot_base": 0,
-                        "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_kmer": narrow_lines(finfos), "shares": None})
+                        "tag": f"full/{args.full_shard_world}/{args.full_shard_rank}", "narrow_lines_per_byte": narrow_lines(finfos), "shares": None})
             fs_steps = max(3, min(args.steps, 10))
             full_shard = {"workload": f"rank {args.full_shard_rank} of {args.full_shard_world} of batches_full.txt (305 batches, 1.06 TB, 82 741 row "
                                       f"bytes per k-mer): {len(fsub)} batches, {sum(sh.index_bytes for sh in fsub) / 1e9:.1f} GB on disk, "
@@ -826,6 +913,8 @@ def main():
         "roofline_narrow": sum_head["roofline_narrow"],
         "arithmetic": "bitwise AND / carry-save adders on u32 words (bit-sliced per-document counters), u64 integer hashing",
         other: sum_other,
+        "unique_rows": unique_rows,
+        "argannot": argannot,
         "clustered": clustered,
         "l31": l31,
         "full_shard": full_shard,
@@ -859,10 +948,22 @@ def main():
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
-    if ok and rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,
-                                           args.cpu_target_s, args.cpu_sample_gb, log)
-        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    # the CPU path is timed in the same run at every N (north_star): rank 0 runs it on the host's cores while the other ranks
+    # sleep on a key of the rendezvous store (a socket wait: no GPU work queued, no core spinning beside the CPU threads)
+    if ok and not args.no_cpu_baseline:
+        if rank == 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,
+                                                   args.cpu_target_s, args.cpu_sample_gb, log)
+                out["cpu_baseline"]["timed_while"] = ("the only process on the host" if world == 1 else
+                                                      f"the other {world - 1} ranks slept on a rendezvous-store key, GPUs idle")
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            finally:
+                if world > 1:
+                    rendezvous_store().set("bench/cpu_baseline_done", "1")
+        elif world > 1:
+            from datetime import timedelta
+            rendezvous_store().wait(["bench/cpu_baseline_done"], timedelta(seconds=1500))
     elif rank == 0:
         out["cpu_baseline"] = None
     if ok and rank == 0:

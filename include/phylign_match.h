@@ -137,7 +137,9 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * "cobs_threshold_rule" (default 0) / "cobs_tie_order" (default 0): the two rules of `cobs query` that no file of the
  * reference pins -- how -t becomes a minimum score: 0 = ceil(t x k-mers), 1 = floor, 2 = round half up; how documents of
  * equal score are listed: 0 = ascending document index, 1 = descending.  The defaults are upstream's as recalled
- * (DESIGN.md section 6); tools/pin_against_cobs.sh checks them against a real cobs 0.2.1. */
+ * (DESIGN.md section 6); tools/pin_against_cobs.sh checks them against a real cobs 0.2.1.  Neither rule can be changed
+ * while a pm_result_t is alive (PM_EINVAL): the device orders a search's records under the rule in force when it was
+ * queued, the host orders and formats them under the current one. */
 int  pm_set_option(const char* name, int64_t value);
 /* ceil(threshold * num_terms): the score a document must reach (cobs -t). */
 uint32_t pm_threshold_terms(double threshold, uint64_t num_terms);

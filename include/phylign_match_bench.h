@@ -46,6 +46,10 @@ void pm_bench_hashes_free(pm_bench_hashes_t* h);
  * own species (many documents near the threshold, long hit lists). */
 int pm_bench_index_plant_cluster(pm_index_t* idx, const pm_bench_hashes_t* h, uint32_t q_first, uint32_t q_step, uint64_t seed);
 
+/* SURVEY.md 8d, many-queries regime: the number of DISTINCT signature rows the query set's k-mers map to in this index
+ * (unique_rows x row_bytes is what a scan with perfect row reuse would have to read; reported beside the algorithmic bytes) */
+int pm_bench_unique_rows(const pm_index_t* idx, const pm_bench_hashes_t* h, uint64_t* unique_rows);
+
 /* writes a resident classic index back as a .cobs_classic file (for the cold / cached / resident timings of the stage
  * on 661k-shaped files: tools/e2e_cold_warm.py) */
 int pm_bench_index_save(const pm_index_t* idx, const char* path);

@@ -21,6 +21,7 @@ SYMBOLS = [
     ("pm_bench_hashes_free", None, [_P]),
     ("pm_bench_index_plant_cluster", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("pm_bench_index_save", C.c_int, [_P, C.c_char_p]),
+    ("pm_bench_unique_rows", C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     ("pm_bench_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 ]
 _aids = None
@@ -82,13 +83,24 @@ class Hashes:
             pass
 
 
-def index_plant_cluster(index, queries, q_first, q_step, seed=97):
+def _hashes_of(index, queries):
     info = index.info
     key = (int(info.canonicalize), int(info.num_hashes))
     cache = queries.__dict__.setdefault("_aid_hashes", {})
     if key not in cache:
         cache[key] = Hashes(queries, *key)
-    _chk(load().pm_bench_index_plant_cluster(index._h, cache[key]._h, q_first, q_step, seed))
+    return cache[key]
+
+
+def index_plant_cluster(index, queries, q_first, q_step, seed=97):
+    _chk(load().pm_bench_index_plant_cluster(index._h, _hashes_of(index, queries)._h, q_first, q_step, seed))
+
+
+def unique_rows(index, queries):
+    """distinct signature rows of `index` that the k-mers of `queries` map to (many-queries regime)"""
+    n = C.c_uint64()
+    _chk(load().pm_bench_unique_rows(index._h, _hashes_of(index, queries)._h, C.byref(n)))
+    return n.value
 
 
 def probe_gather(index, n_groups, lookups_per_group, mode=None, flavor=None, unroll=None):

@@ -456,6 +456,51 @@ extern "C" int pm_bench_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
     return PM_OK;
 }
 
+// SURVEY.md 8d "many-queries regime": the DISTINCT signature rows a query set touches in this index.  A bitmap of S
+// bits is marked with one atomicOr per (k-mer, hash function) and counted; untimed, reporting only.
+__global__ __launch_bounds__(256) void k_mark_rows(uint32_t* __restrict__ bitmap, const uint64_t* __restrict__ hashes,
+                                                   uint64_t n, uint64_t S, uint64_t bm) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = mod_sig(hashes[i], S, bm);
+        atomicOr(bitmap + (r >> 5), 1u << (r & 31));
+    }
+}
+__global__ __launch_bounds__(256) void k_count_bits(const uint32_t* __restrict__ bitmap, uint64_t n_words,
+                                                    unsigned long long* __restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+        c += (unsigned)__popc(bitmap[i]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+extern "C" int pm_bench_unique_rows(const pm_index_t* ix, const pm_bench_hashes_t* h, uint64_t* unique_rows) {
+    if (!ix || !h || !unique_rows) return bfail(PM_EINVAL, "bad argument");
+    uint8_t* m = nullptr; uint64_t stride = 0; pm_index_info_t info;
+    { int rc = bind_to(ix, &m, &stride, &info); if (rc) return rc; }
+    if (info.num_hashes != h->nh || (int)info.canonicalize != h->canon)
+        return bfail(PM_EINVAL, "the hashes were made for canonicalize %d, %u hash functions; the index has %u, %u",
+                     h->canon, h->nh, info.canonicalize, info.num_hashes);
+    const uint64_t S = info.signature_size, n_words = (S + 31) / 32, n = h->n_terms * h->nh;
+    uint32_t* bitmap = nullptr; unsigned long long* d_out = nullptr;
+    BHIP(hipMalloc((void**)&bitmap, n_words * 4 + 8));
+    d_out = reinterpret_cast<unsigned long long*>(bitmap + ((n_words + 1) & ~1ull));
+    hipError_t e = hipMemsetAsync(bitmap, 0, n_words * 4 + 8, nullptr);
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_mark_rows, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536)), dim3(256), 0, nullptr,
+                           bitmap, h->d_hashes, n, S, barrett_m(S));
+        hipLaunchKernelGGL(k_count_bits, dim3((uint32_t)std::min<uint64_t>((n_words + 255) / 256, 65536)), dim3(256), 0, nullptr,
+                           bitmap, n_words, d_out);
+        e = hipGetLastError();
+    }
+    unsigned long long got = 0;
+    if (e == hipSuccess) e = hipMemcpy(&got, d_out, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(bitmap);
+    if (e != hipSuccess) return bfail(PM_EHIP, "unique rows: %s", hipGetErrorString(e));
+    *unique_rows = got;
+    return PM_OK;
+}
+
 // rows of `stride` bytes -> packed rows of row_bytes (the file's layout), one byte per thread step
 __global__ __launch_bounds__(256) void k_unstride(const uint8_t* __restrict__ src, uint64_t stride, uint64_t row_bytes,
                                                   uint64_t total, uint8_t* __restrict__ dst) {

@@ -33,12 +33,14 @@
 
 using namespace pm;
 
-// counter-width classes: queries of < 2^3, 2^7, 2^10, 2^16, 2^20, 2^24 k-mers get bit-sliced per-document
+// counter-width classes: queries of < 2^3, 2^7, 2^10, 2^13, 2^16, 2^20, 2^24 k-mers get bit-sliced per-document
 // counters of that many planes (one k_scan instantiation each), so short reads never pay for a
 // long gene or plasmid in the same FASTA, and a query of 1 ... 7 k-mers (BASELINE configs[1]: "31-mer
-// queries" = one k-mer each, hit <=> bit set) carries three planes instead of seven
-constexpr int kNumClasses = 6;
-static const int kPlaneClass[kNumClasses] = {3, 7, 10, 16, 20, 24};
+// queries" = one k-mer each, hit <=> bit set) carries three planes instead of seven.  The 13-plane class is the
+// gene class (data/ARGannot_r3.fa, 207 ... 3 123 k-mers per gene): it is the widest counter that
+// still fits 128 VGPRs (4 waves per SIMD) without scratch; the 16-plane class above it spills 5-14 registers.
+constexpr int kNumClasses = 7;
+static const int kPlaneClass[kNumClasses] = {3, 7, 10, 13, 16, 20, 24};
 
 // ------------------------------------------------------------------ errors
 // sets the calling thread's pm_last_error() text, returns `code`
@@ -160,6 +162,8 @@ void parallel_for(size_t n, const std::function<void(size_t)>& fn);
 size_t parallel_width();                    // worker threads + the caller (<= 16)
 // pm_index.cpp: pooled staging buffers of the parallel file loader (released by pm_shutdown)
 void release_stage_pool();
+void release_query_pool();                   // pm_queries.cpp: device buffers of released query sets
+int query_buf_take(size_t bytes, void** out);   // a device buffer of a query set (pooled; given back by pm_queries_release_device)
 void release_text_pool();                    // pm_text.cpp: the pooled text / gzip buffers of the 03_match writer
 // pm_gzfast.cpp: text[0, n) (n < 2^31) as one gzip member -- fixed-Huffman deflate, line-structured matches -- written
 // to out[0, gz_fast_bound(n)); returns the member's length
@@ -184,6 +188,7 @@ extern uint32_t g_wq_split;
 extern uint32_t g_threshold_rule;
 // pm_set_option("cobs_tie_order"): 1 = documents of equal score are listed by DESCENDING index (default 0: ascending)
 extern uint32_t g_tie_desc;
+extern std::atomic<int> g_live_results;      // pm_search.cpp: results not yet freed
 // pm_set_option("merge_counting_sort") (default 1): (slot, query) groups written as several runs are merged by the
 // O(records + runs) counting sort where it applies; 0 = always the O(records x runs x log) form (A/B, tests)
 extern uint32_t g_merge_hist;

@@ -491,27 +491,37 @@ extern "C" int pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index
 } PM_GUARD_END
 // The decode-once cache of a compressed index (the reference's `mem-disk` mode with
 // keep_cobs_indexes, Snakefile:364-387): while the stream (`xzcat` pipe) is loaded into HBM every byte read is also
-// written to "<tee_path>.tmp", which becomes `tee_path` once the whole index has arrived -- a later run finds the plain
-// file and takes the parallel pread path instead of decoding again.  A failed load leaves no file behind; a failed
-// WRITE (disk full) does not fail the load: the index is resident, only the cache file is dropped (*cached = 0).
+// written to a temporary file of this call's own ("<tee_path>.XXXXXX.tmp", mkstemps: two processes decoding the same
+// batch into one cache directory never share an inode), which becomes `tee_path` once the whole index has arrived and
+// the file on disk has exactly the bytes that were read -- a later run finds the plain file and takes the parallel pread
+// path instead of decoding again.  When another process published the same index first, this call's copy is dropped.  A
+// failed load leaves no file behind; a failed WRITE (disk full) does not fail the load: the index is resident, only
+// the cache file is dropped (*cached = 0).
 extern "C" int pm_index_load_fd_tee(int fd, uint64_t size_hint, int layout, const char* tee_path, int* cached, pm_index_t** out) try {
     NEED_DEV();
     if (!out || fd < 0 || !tee_path) return fail(PM_EINVAL, "bad argument");
     if (cached) *cached = 0;
-    const std::string tmp = std::string(tee_path) + ".tmp";
+    std::string tmp = std::string(tee_path) + ".XXXXXX.tmp";
     Reader rd; rd.fd = fd;
-    rd.tee_fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    rd.tee_fd = mkstemps(&tmp[0], 4);                          // O_CREAT | O_EXCL, a name of this call's own
     if (rd.tee_fd < 0) rd.tee_errno = errno;                  // no cache file: the load itself goes on
+    else (void)fchmod(rd.tee_fd, 0644);
     int rc = load_from_reader(rd, size_hint, layout, false, out);
     bool ok = rc == PM_OK && rd.tee_fd >= 0 && !rd.tee_errno;
     if (ok) {
-        // the index ends where its matrix ends: the cache file must hold exactly header + matrix bytes
+        // the index ends where its matrix ends: the cache file must hold exactly header + matrix bytes, all of them on disk
         pm_index_info_t in = (*out)->info;
-        ok = in.n_parts == 0 && rd.tee_bytes >= in.signature_size * in.row_bytes;
+        struct stat sb;
+        ok = in.n_parts == 0 && rd.tee_bytes >= in.signature_size * in.row_bytes &&
+             fstat(rd.tee_fd, &sb) == 0 && (uint64_t)sb.st_size == rd.tee_bytes;
     }
     if (rd.tee_fd >= 0) { if (close(rd.tee_fd) != 0) ok = false; }
-    if (ok && rename(tmp.c_str(), tee_path) != 0) ok = false;
-    if (!ok) (void)unlink(tmp.c_str());
+    if (ok) {
+        struct stat sb;
+        if (stat(tee_path, &sb) == 0 && (uint64_t)sb.st_size == rd.tee_bytes) (void)unlink(tmp.c_str());   // published by another process meanwhile
+        else if (rename(tmp.c_str(), tee_path) != 0) ok = false;
+    }
+    if (!ok && rd.tee_fd >= 0) (void)unlink(tmp.c_str());
     if (cached) *cached = ok ? 1 : 0;
     return rc;
 } PM_GUARD_END

@@ -65,7 +65,7 @@ hipError_t launch_hash_terms(const uint8_t* seq, const QDesc* qd, const uint32_t
                              uint64_t n_slots, uint32_t k, int canon, uint32_t nh,
                              uint64_t* hashes, hipStream_t st);
 // g = lanes per row (1..64 pow2; 0 = mixed, taken per batch from BatchDesc.lanes),
-// planes = counter bit planes (3,7,10,16,20,24);
+// planes = counter bit planes (3,7,10,13,16,20,24);
 // slabs > 1 only with n_batches == 1 (rows wider than 1024 B)
 hipError_t launch_scan(const ScanArgs& a, int g, int planes, uint32_t slabs, hipStream_t st);
 uint32_t scan_queries_per_block(int g, uint32_t wq_groups);   // wq_groups = 0: plain form

@@ -279,7 +279,7 @@ __device__ __forceinline__ u32x4 ld_row(const uint8_t* p) {
 // is off in this form (partial counts say nothing about a document's total); group 0 of the
 // query runs the usual epilogue on the combined planes.  Results are identical to the plain form.
 template <int G, int P, bool NH1, bool WQ>
-__global__ __launch_bounds__(256, (P <= 10 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : (P <= 20 ? PM_SCAN_WAVES_P20 : PM_SCAN_WAVES_P24)))) void k_scan(const ScanArgs a)
+__global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : (P <= 20 ? PM_SCAN_WAVES_P20 : PM_SCAN_WAVES_P24)))) void k_scan(const ScanArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -717,6 +717,7 @@ static hipError_t scan_dispatch_p(const ScanArgs& a, int planes, uint32_t slabs,
         case 3:  return scan_dispatch_nh<G, 3>(a, slabs, st);
         case 7:  return scan_dispatch_nh<G, 7>(a, slabs, st);
         case 10: return scan_dispatch_nh<G, 10>(a, slabs, st);
+        case 13: return scan_dispatch_nh<G, 13>(a, slabs, st);
         case 16: return scan_dispatch_nh<G, 16>(a, slabs, st);
         case 20: return scan_dispatch_nh<G, 20>(a, slabs, st);
         case 24: return scan_dispatch_nh<G, 24>(a, slabs, st);

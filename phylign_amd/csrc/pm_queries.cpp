@@ -50,7 +50,9 @@ static int finish_queries(pm_queries* q) {
         uint64_t b0 = q->qd[i].pad_blk, nb = (q->n_terms[i] + 7) / 8;
         for (uint64_t b = 0; b < nb; ++b) blkq[(size_t)(b0 + b)] = (uint32_t)i;
     }
-    // plane classes (counter width): stable partition of query ids by class
+    // plane classes (counter width): query ids partitioned by class; inside a class the longest queries come first
+    // (ties in file order).  A wavefront runs as long as its longest query, so neighbours in qmap should be of similar
+    // length, and the long ones should not be the last to start.  Reads of one length (config 3) keep their file order.
     auto cls = [](uint32_t nt) {
         for (int c = 0; c < kNumClasses; ++c) if (nt < (1u << kPlaneClass[c])) return c;
         return kNumClasses - 1;
@@ -58,7 +60,16 @@ static int finish_queries(pm_queries* q) {
     q->qmap.reserve(nq);
     for (int c = 0; c < kNumClasses; ++c) {
         q->class_begin[c] = (uint32_t)q->qmap.size();
-        for (size_t i = 0; i < nq; ++i) if (cls(q->n_terms[i]) == c) q->qmap.push_back((uint32_t)i);
+        bool mixed = false;
+        uint32_t first_nt = 0;
+        for (size_t i = 0; i < nq; ++i) if (cls(q->n_terms[i]) == c) {
+            if (q->qmap.size() == q->class_begin[c]) first_nt = q->n_terms[i];
+            else if (q->n_terms[i] != first_nt) mixed = true;
+            q->qmap.push_back((uint32_t)i);
+        }
+        if (mixed)
+            std::stable_sort(q->qmap.begin() + q->class_begin[c], q->qmap.end(),
+                             [&](uint32_t x, uint32_t y) { return q->n_terms[x] > q->n_terms[y]; });
     }
     q->class_begin[kNumClasses] = (uint32_t)q->qmap.size();
     q->blkq.swap(blkq);
@@ -335,13 +346,72 @@ extern "C" int pm_queries_terms(const pm_queries_t* q, uint64_t i, uint64_t* n_t
     *n_terms = q->n_terms[(size_t)i];
     return PM_OK;
 } PM_GUARD_END
-static void drop_device_state(pm_queries* q) {
-    if (q->d_seq) (void)hipFree(q->d_seq);
-    if (q->d_qd) (void)hipFree(q->d_qd);
-    if (q->d_blkq) (void)hipFree(q->d_blkq);
-    if (q->d_qmap) (void)hipFree(q->d_qmap);
-    if (q->d_thr) (void)hipFree(q->d_thr);
-    for (auto& h : q->hashes) if (h.d) (void)hipFree(h.d);
+// HBM copies of query sets come from a small pool and go back to it.  hipFree waits for the whole device -- for the
+// scan of the NEXT (group, chunk) unit that match_stage has queued already -- so a chunk of a large query file that gives
+// its device copies back (pm_queries_release_device) would otherwise serialise the chunk pipeline to depth one.  The
+// next chunk is of about the same size and takes the buffers over.  At most kQPoolMax buffers wait here; beyond that
+// the smallest one is really freed.  release_query_pool(): pm_shutdown.
+namespace {
+struct QBuf { void* p; size_t bytes; };
+std::mutex g_qpool_mu;
+std::vector<QBuf> g_qpool;
+constexpr size_t kQPoolMax = 16;
+}
+int query_buf_take(size_t bytes, void** out) {
+    bytes = std::max<size_t>(bytes, 256);
+    {
+        std::lock_guard<std::mutex> lk(g_qpool_mu);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < g_qpool.size(); ++i)
+            if (g_qpool[i].bytes >= bytes && g_qpool[i].bytes <= bytes + bytes / 2 + 4096 &&
+                (best == SIZE_MAX || g_qpool[i].bytes < g_qpool[best].bytes)) best = i;
+        if (best != SIZE_MAX) {
+            *out = g_qpool[best].p;
+            g_qpool.erase(g_qpool.begin() + (long)best);
+            return PM_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {                     // what waits in the pool may be what is missing
+        release_query_pool();
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "hipMalloc(%zu bytes) for a query set: %s", bytes, hipGetErrorString(e));
+    return PM_OK;
+}
+// bytes = what qbuf_take was asked for (the pool keeps the allocation's real size only approximately: never less)
+static void qbuf_give(void* p, size_t bytes) {
+    if (!p) return;
+    QBuf b{p, std::max<size_t>(bytes, 256)};
+    {
+        std::lock_guard<std::mutex> lk(g_qpool_mu);
+        if (g_ctx.ready) {
+            g_qpool.push_back(b);
+            if (g_qpool.size() <= kQPoolMax) return;
+            size_t small = 0;
+            for (size_t i = 1; i < g_qpool.size(); ++i) if (g_qpool[i].bytes < g_qpool[small].bytes) small = i;
+            b = g_qpool[small];
+            g_qpool.erase(g_qpool.begin() + (long)small);
+        }
+    }
+    (void)hipFree(b.p);
+}
+void release_query_pool() {
+    std::vector<QBuf> all;
+    { std::lock_guard<std::mutex> lk(g_qpool_mu); all.swap(g_qpool); }
+    for (auto& b : all) (void)hipFree(b.p);
+}
+// free_now: the device is going away or the caller wants the memory back for good (pm_queries_free); otherwise the
+// buffers wait in the pool for the next query set
+static void drop_device_state(pm_queries* q, bool free_now) {
+    const size_t nq = q->headers.size();
+    auto give = [&](void* p, size_t bytes) { if (!p) return; if (free_now) (void)hipFree(p); else qbuf_give(p, bytes); };
+    give(q->d_seq, q->seqs.size() + 64);
+    give(q->d_qd, nq * sizeof(QDesc));
+    give(q->d_blkq, std::max<size_t>(q->blkq.size(), 1) * 4);
+    give(q->d_qmap, nq * 4);
+    give(q->d_thr, nq * 4);
+    for (auto& h : q->hashes) give(h.d, (size_t)(q->n_slots * h.nh * 8));
     q->d_seq = nullptr; q->d_qd = nullptr; q->d_blkq = nullptr; q->d_qmap = nullptr; q->d_thr = nullptr;
     q->thr_for = -1.0;
     q->hashes.clear();
@@ -351,7 +421,7 @@ extern "C" void pm_queries_free(pm_queries_t* q) {
     if (!q) return;
     bind_thread_quiet();
     if (g_ctx.ready && q->on_device) (void)hipStreamSynchronize(g_ctx.stream);   // a search in flight may still read them
-    drop_device_state(q);
+    drop_device_state(q, true);
     if (q->last_use) (void)hipEventDestroy(q->last_use);
     delete q;
 }
@@ -365,7 +435,7 @@ extern "C" int pm_queries_release_device(pm_queries_t* q) try {
     NEED_DEV();
     if (q->last_use) HIPCHK(hipEventSynchronize(q->last_use));
     else HIPCHK(hipStreamSynchronize(g_ctx.stream));
-    drop_device_state(q);
+    drop_device_state(q, false);                  // into the pool: no hipFree, nothing waits for the searches queued behind
     return PM_OK;
 } PM_GUARD_END
 // *resident: HBM bytes the query set holds right now; *when_searched: what it holds while it is searched against indexes
@@ -388,11 +458,12 @@ int upload_queries(pm_queries* q) {
     if (q->on_device) return PM_OK;
     const size_t nq = q->headers.size();
     if (nq) {
-        HIPCHK(hipMalloc((void**)&q->d_seq, q->seqs.size() + 64));
-        HIPCHK(hipMemset(q->d_seq, 0, q->seqs.size() + 64));
-        HIPCHK(hipMalloc((void**)&q->d_qd, nq * sizeof(QDesc)));
-        HIPCHK(hipMalloc((void**)&q->d_blkq, std::max<size_t>(q->blkq.size(), 1) * 4));
-        HIPCHK(hipMalloc((void**)&q->d_qmap, nq * 4));
+        int rc;
+        if ((rc = query_buf_take(q->seqs.size() + 64, (void**)&q->d_seq))) return rc;
+        HIPCHK(hipMemset(q->d_seq + q->seqs.size(), 0, 64));          // the padding behind the sequences
+        if ((rc = query_buf_take(nq * sizeof(QDesc), (void**)&q->d_qd))) return rc;
+        if ((rc = query_buf_take(std::max<size_t>(q->blkq.size(), 1) * 4, (void**)&q->d_blkq))) return rc;
+        if ((rc = query_buf_take(nq * 4, (void**)&q->d_qmap))) return rc;
         HIPCHK(hipMemcpy(q->d_seq, q->seqs.data(), q->seqs.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(q->d_qd, q->qd.data(), nq * sizeof(QDesc), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(q->d_blkq, q->blkq.data(), q->blkq.size() * 4, hipMemcpyHostToDevice));
@@ -411,7 +482,7 @@ int ensure_hashes(pm_queries* q, int canon, uint32_t nh, uint64_t** out) {
     if (!hb) {
         q->hashes.push_back({canon, nh, nullptr, ~0ull});
         hb = &q->hashes.back();
-        if (q->n_slots) HIPCHK(hipMalloc((void**)&hb->d, q->n_slots * nh * 8));
+        if (q->n_slots) { int rc = query_buf_take((size_t)(q->n_slots * nh * 8), (void**)&hb->d); if (rc) return rc; }
     }
     if (hb->epoch != q->epoch) {
         HIPCHK(launch_hash_terms(q->d_seq, q->d_qd, q->d_blkq, q->n_slots, q->k, canon, nh, hb->d, g_ctx.stream));

@@ -154,6 +154,7 @@ extern "C" void pm_shutdown(void) {
     }
     release_stage_pool();
     release_text_pool();
+    release_query_pool();
     for (auto& b : g_ctx.free_hits) (void)hipFree(b.p);
     if (g_ctx.d_fetch) (void)hipFree(g_ctx.d_fetch);
     for (auto& b : g_ctx.free_pinned) (void)hipHostFree(b.p);
@@ -194,12 +195,16 @@ extern "C" int pm_set_option(const char* name, int64_t value) try {
     // that the day a cobs 0.2.1 binary says otherwise (tools/pin_against_cobs.sh) no code changes
     if (strcmp(name, "cobs_threshold_rule") == 0) {
         if (value < 0 || value > 2) return fail(PM_EINVAL, "cobs_threshold_rule takes 0 (ceil), 1 (floor) or 2 (round half up)");
+        if ((uint32_t)value != g_threshold_rule && g_live_results.load() > 0)
+            return fail(PM_EINVAL, "cobs_threshold_rule cannot change while %d search result(s) are alive (free them first)", g_live_results.load());
         g_threshold_rule = (uint32_t)value;
         return PM_OK;
     }
     if (strcmp(name, "merge_counting_sort") == 0) { g_merge_hist = value ? 1u : 0u; return PM_OK; }
     if (strcmp(name, "cobs_tie_order") == 0) {
         if (value < 0 || value > 1) return fail(PM_EINVAL, "cobs_tie_order takes 0 (equal scores by ascending document) or 1 (descending)");
+        if ((uint32_t)value != g_tie_desc && g_live_results.load() > 0)
+            return fail(PM_EINVAL, "cobs_tie_order cannot change while %d search result(s) are alive (free them first)", g_live_results.load());
         g_tie_desc = (uint32_t)value;
         return PM_OK;
     }

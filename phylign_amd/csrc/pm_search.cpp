@@ -111,7 +111,15 @@ static inline void part_range(const pm_qpart_t& p, uint32_t n, uint32_t* first, 
     *end = (uint32_t)((uint64_t)p.hi * n / p.den);
 }
 
+// results alive: the two switchable cobs rules are captured per search for the device-side ordering, while the host
+// comparator (hit_less) and pm_threshold_terms read the process-wide setting -- pm_set_option refuses to change either
+// rule while a result exists, so the two can never disagree about records that are still around
+std::atomic<int> g_live_results{0};
 struct pm_result {
+    pm_result() { g_live_results.fetch_add(1, std::memory_order_relaxed); }
+    ~pm_result() { g_live_results.fetch_sub(1, std::memory_order_relaxed); }
+    pm_result(const pm_result&) = delete;
+    pm_result& operator=(const pm_result&) = delete;
     // what was asked (kept for the one re-run after a hit-buffer overflow)
     std::vector<pm_index_t*> idx;
     pm_queries* q = nullptr;
@@ -313,7 +321,7 @@ static int enqueue_search(pm_result* r, uint64_t want_cap) {
     if (nq && (!q->d_thr || q->thr_for != r->threshold || q->thr_rule != g_threshold_rule)) {
         std::vector<uint32_t> thr(nq);
         for (size_t i = 0; i < nq; ++i) thr[i] = r->threshold == 0.0 ? 0u : pm_threshold_terms(r->threshold, q->n_terms[i]);
-        if (!q->d_thr) HIPCHK(hipMalloc((void**)&q->d_thr, nq * 4));
+        if (!q->d_thr) { int trc = query_buf_take(nq * 4, (void**)&q->d_thr); if (trc) return trc; }
         HIPCHK(hipStreamSynchronize(st));                 // an earlier search in flight may still read the old values
         HIPCHK(hipMemcpy(q->d_thr, thr.data(), nq * 4, hipMemcpyHostToDevice));
         q->thr_for = r->threshold; q->thr_rule = g_threshold_rule;

@@ -38,23 +38,33 @@ def rank_env(rank, world, port, environ=None):
     return env
 
 
-def _child_setup():
-    """between fork and exec of a rank: own process group (ended as a group), and SIGTERM should the parent die first
-    (a killed parent must not leave ranks holding GPUs)"""
-    os.setsid()
-    try:
-        import ctypes
-        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
-    except Exception:
-        pass
+def arm_parent_death_signal():
+    """called by a rank at its own start-up (bench.py, match_stage: before anything else runs) when the launcher below
+    started it: SIGTERM should the launcher die first -- a killed parent must not leave ranks holding GPUs.  Done here, in
+    the child's own interpreter, not between fork and exec of a parent that may already run threads."""
+    if os.environ.get("PHYLIGN_LAUNCHER_PID"):
+        try:
+            import ctypes
+            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
+            if os.getppid() != int(os.environ["PHYLIGN_LAUNCHER_PID"]):                   # it died before we got here
+                os.kill(os.getpid(), signal.SIGTERM)
+        except Exception:
+            pass
 
 
 def spawn_ranks(cmd, world, poll_s=0.2, grace_s=10.0, extra_env=None):
     """Runs `cmd` (argv list) once per rank and waits.  Returns the exit status of the job: 0 when every rank
-    returned 0, else the first failing rank's status (a rank killed by signal n counts as 128 + n)."""
+    returned 0, else the first failing rank's status (a rank killed by signal n counts as 128 + n).  A failing rank, or
+    SIGINT / SIGTERM to the launcher, ends the others the same way: SIGTERM to their process groups, `grace_s` seconds,
+    then SIGKILL -- a rank stuck in a collective does not keep its GPU.
+    (MASTER_PORT is a port that was free a moment ago: between free_port() and rank 0's bind another process could take
+    it; the launchers of the driver pass their own --master-port, this path is the convenience form.)"""
     port = free_port()
-    procs = [subprocess.Popen(cmd, env=dict(rank_env(r, world, port), **(extra_env or {})), preexec_fn=_child_setup)
+    launcher = {"PHYLIGN_LAUNCHER_PID": str(os.getpid())}
+    # start_new_session: every rank leads its own process group (ended as a group); no code runs between fork and exec
+    procs = [subprocess.Popen(cmd, env=dict(rank_env(r, world, port), **launcher, **(extra_env or {})), start_new_session=True)
              for r in range(world)]
+    stop = []                                             # signal numbers received by the launcher
 
     def end_all(sig):
         for p in procs:
@@ -64,36 +74,43 @@ def spawn_ranks(cmd, world, poll_s=0.2, grace_s=10.0, extra_env=None):
                 except (ProcessLookupError, PermissionError):
                     pass
 
-    def on_signal(signum, _frame):
+    def term_then_kill():
         end_all(signal.SIGTERM)
-        sys.exit(128 + signum)
-    old = {s: signal.signal(s, on_signal) for s in (signal.SIGINT, signal.SIGTERM)}
+        t_end = time.time() + grace_s
+        while time.time() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(poll_s)
+        end_all(signal.SIGKILL)
+
+    old = {s: signal.signal(s, lambda signum, _frame: stop.append(signum)) for s in (signal.SIGINT, signal.SIGTERM)}
     status = 0
     try:
         while True:
+            if stop:
+                status = 128 + stop[0]
+                sys.stderr.write(f"[launch] signal {stop[0]}: ending the ranks\n")
+                term_then_kill()
+                break
             codes = [p.poll() for p in procs]
             bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
             if bad:
                 r, c = bad[0]
                 status = 128 - c if c < 0 else c
                 sys.stderr.write(f"[launch] rank {r} exited with status {c}: ending the other ranks\n")
-                end_all(signal.SIGTERM)
-                t_end = time.time() + grace_s
-                while time.time() < t_end and any(p.poll() is None for p in procs):
-                    time.sleep(poll_s)
-                end_all(signal.SIGKILL)
+                term_then_kill()
                 break
             if all(c == 0 for c in codes):
                 break
             time.sleep(poll_s)
     finally:
+        if any(p.poll() is None for p in procs):          # an exception in the loop above: nobody is left behind
+            term_then_kill()
         for p in procs:
             try:
                 p.wait(timeout=grace_s)
             except subprocess.TimeoutExpired:
                 pass
-        for s, h in old.items():
-            signal.signal(s, h)
+        for s_, h in old.items():
+            signal.signal(s_, h)
     return status
 
 

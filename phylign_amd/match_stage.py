@@ -139,13 +139,16 @@ class FileSource:
         try:
             fobj, proc = open_index_stream(self.cobs_dir, batch, self.cache_dir)
             tee = os.path.join(self.cache_dir, f"{batch}.cobs_classic") if (self.cache_dir and proc is not None) else None
+            ix = None
             try:
                 ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0), tee_path=tee)
             finally:
                 fobj.close()
                 if proc is not None and proc.wait() != 0:
-                    if tee and os.path.exists(tee):
-                        os.unlink(tee)                      # whatever the decoder choked on is not a cache entry
+                    # whatever the decoder choked on is not a cache entry -- but only the file THIS load published is
+                    # removed (another process decoding the same batch writes its own temporary and may have finished well)
+                    if tee and ix is not None and getattr(ix, "cached", False) and os.path.exists(tee):
+                        os.unlink(tee)
                     raise RuntimeError(f"xzcat failed on batch {batch}")
         finally:
             if mb:
@@ -362,8 +365,9 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
         res.free()
         if nc > 1:
             # the chunk is searched again only with the next group: its HBM copies (sequences, 8 bytes per k-mer of hashes) go
-            # now, the host side stays for the texts and the merge.  (Waits for nothing: this unit's search has finished and
-            # the unit queued behind it uses another chunk.)
+            # back to the library's pool now (the next chunk takes them over), the host side stays for the texts and the
+            # merge.  Waits for nothing: this unit's search has finished, the unit queued behind it uses another chunk, and
+            # no hipFree -- which would wait for that queued scan -- is involved.
             qc.release_device()
         if ci == nc - 1:                                 # the group has seen every chunk: its matrices may go
             for pos, ix, held in group:
@@ -525,7 +529,7 @@ def bind_rank_to_gpu(local_rank, n_visible):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap = argparse.ArgumentParser(allow_abbrev=False, description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--batches", default=None)
     ap.add_argument("--cobs-dir", default=None)
     ap.add_argument("--sizes", default=None, help="data/decompressed_indexes_sizes.txt")
@@ -597,6 +601,7 @@ def main(argv=None):
     if launch.wants_self_launch(args.gpus):
         # this process has not touched the GPU: start the ranks as children, relay their status
         sys.exit(launch.self_launch_module("phylign_amd.match_stage", sys.argv[1:] if argv is None else argv, args.gpus))
+    launch.arm_parent_death_signal()          # a rank of that launcher: ends with it
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

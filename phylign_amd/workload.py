@@ -213,6 +213,52 @@ def make_queries(n, length=150, seed=31):
     return b"".join(parts), seqs
 
 
+_ARGANNOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "argannot", "lengths.txt")
+
+
+def argannot_lengths(path=_ARGANNOT):
+    """sequence lengths of the 1 856 records of the reference's data/ARGannot_r3.fa in file order (SURVEY.md 8d's third
+    query shape: genes of 237 ... 3 153 bp, 1 594 532 31-mers); the committed fixture is lengths only
+    (tools/gen_golden_argannot.py)"""
+    with open(path) as f:
+        return [int(x) for x in f if x.strip() and not x.startswith("#")]
+
+
+def make_queries_lengths(lengths, seed=31, prefix="g"):
+    """uniform ACGT queries of the given lengths, in that order; returns (fasta bytes, list of sequences as bytes)"""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [lut[rng.integers(0, 4, size=int(n), dtype=np.uint8)].tobytes() for n in lengths]
+    parts = []
+    for i, s_ in enumerate(seqs):
+        parts.append(f">{prefix}{i:07d}\n".encode())
+        parts.append(s_)
+        parts.append(b"\n")
+    return b"".join(parts), seqs
+
+
+def plant_plan_ragged(hashes, terms, shapes, every=20, docs_per_query=8, seed=7, threshold=0.7):
+    """plant_plan for queries of different lengths: `terms` = k-mers per query, `hashes` = their seed-0 hashes one query
+    after the other.  The planted fractions straddle the threshold: 1.0, 0.9, 0.8, threshold, threshold - 0.05, 0.6."""
+    rng = np.random.default_rng(seed)
+    fr = [1.0, 0.9, 0.8, threshold, threshold - 0.05, 0.6]
+    off = np.concatenate([[0], np.cumsum(np.asarray(terms, dtype=np.int64))])
+    plan, sure = {}, 0
+    for n, q in enumerate(range(0, len(terms), every)):
+        pos = n % len(shapes)
+        sh = shapes[pos]
+        hq = hashes[off[q]:off[q + 1]]
+        rows_q = (hq % np.uint64(sh.signature_size)).astype(np.uint64)
+        docs = rng.choice(sh.n_docs, size=min(docs_per_query, sh.n_docs), replace=False)
+        for j, d in enumerate(docs):
+            m = int(np.ceil(fr[j % len(fr)] * terms[q]))
+            r, dd = plan.setdefault(pos, ([], []))
+            r.append(rows_q[:m])
+            dd.append(np.full(m, d, dtype=np.uint32))
+            sure += int(m >= np.ceil(threshold * terms[q]))
+    return {p_: (np.concatenate(r), np.concatenate(d)) for p_, (r, d) in plan.items()}, sure
+
+
 def plant_plan(hashes, n_queries, terms_per_query, shapes, every=20, docs_per_query=8, seed=7):
     """Planted true positives: every `every`-th query is planted into one batch
     (round-robin over `shapes`) in `docs_per_query` documents at match fractions

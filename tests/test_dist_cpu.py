@@ -272,6 +272,62 @@ def test_self_launch_starts_fresh_ranks_and_relays_status(tmp_path):
     assert r.returncode == 7 and time.time() - t0 < 30 and b"rank 2 exited with status 7" in r.stderr
 
 
+def test_self_launch_ends_stuck_ranks_when_signalled(tmp_path):
+    """SIGTERM to the launcher: the ranks get SIGTERM, a grace period, then SIGKILL -- a rank that ignores SIGTERM (stuck in
+    a collective) does not outlive the launcher; and a rank whose launcher is killed outright ends by its parent-death signal"""
+    import signal
+    import subprocess
+    import sys
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, signal, sys, time\n"
+        "sys.path.insert(0, sys.argv[2])\n"
+        "from phylign_amd import launch\n"
+        "launch.arm_parent_death_signal()\n"
+        "r = int(os.environ['RANK'])\n"
+        "if r == 1 and sys.argv[3] == 'stubborn':\n"
+        "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "open(os.path.join(sys.argv[1], f'pid{r}'), 'w').write(str(os.getpid()))\n"
+        "time.sleep(120)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom phylign_amd import launch\n"
+            "sys.exit(launch.spawn_ranks([sys.executable, %r] + sys.argv[1:], 3, grace_s=1.5))\n" % (root, str(script)))
+
+    def start(mode):
+        for f in tmp_path.glob("pid*"):
+            f.unlink()
+        p = subprocess.Popen([sys.executable, "-c", code, str(tmp_path), root, mode], stderr=subprocess.PIPE)
+        t_end = time.time() + 30
+        while time.time() < t_end and len(list(tmp_path.glob("pid*"))) < 3:
+            time.sleep(0.05)
+        pids = [int((tmp_path / f"pid{r}").read_text()) for r in range(3)]
+        return p, pids
+
+    def gone(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return True
+        try:                                             # a zombie of a dead parent counts as gone
+            return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] == "Z"
+        except OSError:
+            return True
+    p, pids = start("stubborn")
+    t0 = time.time()
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM and time.time() - t0 < 15
+    assert b"ending the ranks" in p.stderr.read()
+    assert all(gone(pid) for pid in pids)                # the stubborn one was killed after the grace period
+    p, pids = start("plain")
+    p.kill()                                             # no chance to clean up: the ranks' own PDEATHSIG ends them
+    p.wait(timeout=10)
+    t_end = time.time() + 10
+    while time.time() < t_end and not all(gone(pid) for pid in pids):
+        time.sleep(0.1)
+    assert all(gone(pid) for pid in pids)
+
+
 def test_bench_and_stage_self_launch_before_touching_the_gpu():
     """`python bench.py --gpus 2` / `python -m phylign_amd.match_stage --gpus 2` in a box without a GPU: the parent
     starts the ranks (no torch import, no HIP call in the parent), every rank fails loudly, the status is relayed"""
@@ -327,3 +383,14 @@ def test_stage_plan_sizes_loaders_by_the_reference_rules(tmp_path):
     [t.join(timeout=30) for t in ts]
     assert not any(t.is_alive() for t in ts) and ram.held == 0
     assert peak[0] <= 5000 and ram.peak == peak[0]        # (the 5000-MB loader ran alone)
+
+
+def test_match_stage_refuses_abbreviated_options():
+    """--config fills in only the options the command line did not set; which ones it set is read off argv by their full
+    names, so an abbreviation (`--thresh 0.5`) must not be accepted silently and then overwritten by the config file"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--synthetic", "small", "--queries", os.devnull, "--out-dir", os.devnull,
+                        "--thresh", "0.5"], capture_output=True, timeout=120, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 2 and b"unrecognized arguments: --thresh" in r.stderr

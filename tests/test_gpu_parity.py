@@ -63,11 +63,14 @@ CASES = [
 @pytest.fixture
 def rules(request, pm, oracle):
     """(cobs_threshold_rule, cobs_tie_order) set on both the product and the oracle for one test, defaults restored"""
+    import gc
     thr_rule, tie = request.param
+    gc.collect()                        # the rules cannot change while a search result is alive (include/phylign_match.h)
     pm.set_option("cobs_threshold_rule", thr_rule)
     pm.set_option("cobs_tie_order", tie)
     oracle.set_rules(thr_rule, tie)
     yield request.param
+    gc.collect()
     pm.set_option("cobs_threshold_rule", 0)
     pm.set_option("cobs_tie_order", 0)
     oracle.set_rules(0, 0)
@@ -99,9 +102,9 @@ def test_query_text_bit_exact(pm, oracle, case, layout, rules):
 
 
 def test_mixed_lengths_and_plane_classes(pm, oracle):
-    """queries of 1 k-mer ... 1.05 M k-mers in one FASTA: every counter-width class (3/7/10/16/20/24 planes)."""
+    """queries of 1 k-mer ... 1.05 M k-mers in one FASTA: every counter-width class (3/7/10/13/16/20/24 planes)."""
     rng = np.random.default_rng(5)
-    lens = [31, 32, 37, 38, 100, 157, 158, 160, 400, 1053, 1054, 3000, 65565, 65566, 70000, 150, 31, 1048605, 1048606]
+    lens = [31, 32, 37, 38, 100, 157, 158, 160, 400, 1053, 1054, 3000, 8221, 8222, 9000, 65565, 65566, 70000, 150, 31, 1048605, 1048606]
     queries = [(f"g{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
     plant = [(i, int(rng.integers(0, 200)), f) for i in range(len(lens)) for f in (1.0, 0.7, 0.5)]
     index, fasta, _ = build_case(oracle, rng, 200, 9000, queries, plant=plant, density=0.3)
@@ -109,7 +112,39 @@ def test_mixed_lengths_and_plane_classes(pm, oracle):
     for thr in (0.7, 0.28):
         assert pm.query_text(ix, fasta, thr) == oracle.query_file(index, fasta, thr)
     res = pm.search([ix], pm.Queries(fasta), 0.7)
-    assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"3", "7", "10", "16", "20", "24"}
+    assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"3", "7", "10", "13", "16", "20", "24"}
+
+
+@pytest.mark.parametrize("n_docs,S", [(664, 30011), (2300, 9001), (100, 50021)])
+def test_argannot_length_mix(pm, oracle, n_docs, S):
+    """SURVEY.md 8d's third query shape: the 1 856 record lengths of the reference's data/ARGannot_r3.fa in file order
+    (237 ... 3 153 bp: the 10- and the 13-plane counter classes, 1 594 532 k-mers), with planted documents at fractions that
+    straddle the threshold in both classes; text byte-identical to the oracle's in both scan modes, and with the
+    post-filter cut (nb_best_hits) fused on the device"""
+    from phylign_amd import workload as W
+    lens = W.argannot_lengths()
+    assert len(lens) == 1856 and sum(n - 30 for n in lens) == 1594532 and (min(lens), max(lens)) == (237, 3153)
+    rng = np.random.default_rng(n_docs)
+    fasta, seqs = W.make_queries_lengths(lens, seed=77, prefix="gene")
+    queries = [(f"gene{i:07d}", s_.decode()) for i, s_ in enumerate(seqs)]
+    plant = [(qi, int(rng.integers(0, n_docs)), f) for qi in range(0, len(lens), 23) for f in (1.0, 0.9, 0.7, 0.7, 0.69, 0.5)]
+    index, fasta2, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant, density=0.2)
+    assert fasta2 == fasta
+    ix = pm.Index.load_mem(index)
+    exp = oracle.query_file(index, fasta, 0.7)
+    assert exp.count(b"\n") > 1856 + 3 * len(plant) // 6
+    try:
+        for bound in (1, 0):
+            pm.set_option("threshold_bound", bound)
+            assert pm.query_text(ix, fasta, 0.7) == exp
+        q = pm.Queries(fasta)
+        res = pm.search([ix], q, 0.7)
+        assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"10", "13"}
+        cut = pm.search([ix], q, 0.7, nb_best_hits=2)
+        from phylign_amd import postprocess
+        assert pm.format_hits(ix, q, cut.hits(), nb_best_hits=2) == postprocess.filter_text(exp.decode(), 2).encode()
+    finally:
+        pm.set_option("threshold_bound", 1)
 
 
 def test_large_index_file_goes_through_the_parallel_reader(pm, oracle, tmp_path):

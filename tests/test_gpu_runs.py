@@ -207,6 +207,20 @@ def test_names_without_separator_are_cut_on_the_host(pm, oracle):
     assert pm.format_hits(ix, q, got, nb_best_hits=-1) == oracle.query_file(index, fasta, 0.7)
 
 
+def _check_multi_rank_line(line, n):
+    """what makes an N > 1 bench line count as measured: cpu_baseline and roofline present, ranks counted"""
+    cb = line["cpu_baseline"]
+    assert cb and cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and "slept" in cb["timed_while"]
+    assert line["gpu_over_cpu"] > 0
+    rf = line["roofline"]
+    assert rf and rf["bound"] == "hbm" and 0 < rf["frac"] < 1.0 and rf["peak"] == 8000.0 and rf["achieved"] > 0
+    assert rf["traffic"] is None and "1-rank launch" in rf["traffic_note"]
+    assert line["n_gpus"] == n and line["participants"]["ranks"] == n
+    assert "rccl_ranks" in line["participants"]          # null over gloo (these tests), N over RCCL
+    ur = line["unique_rows"]
+    assert ur and 0 < ur["unique_rows_x_row_bytes"] <= ur["algorithmic_bytes_per_step"] and ur["unique_rows"] <= ur["rows_resident"]
+
+
 def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     """the N>1 bench path (static sharding + packed gather, two ranks sharing the GPU over gloo)
     returns exactly the records of the single-rank run"""
@@ -221,6 +235,14 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     assert line["threshold_bound"]["hits_identical_to_headline"] and line["clustered"]["hits_identical"]
     assert line["roofline"]["frac"] < 1.0 and line["threshold_bound"]["roofline"]["frac"] < 1.0
     assert line["clustered"]["fetch_all_rows"]["hits"] > 20 * line["hits"]
+    ur = line["unique_rows"]
+    assert 0 < ur["unique_rows_x_row_bytes"] <= ur["algorithmic_bytes_per_step"] and "perfect row reuse" in ur["label"]
+    ga = line["argannot"]
+    for rep in ("x1", "x8"):
+        g = ga[rep]
+        assert g["hits_identical"] and g["kmers"] == 1594532 * int(rep[1:]) and g["fetch_all_rows"]["hits"] >= g["planted_pairs_at_or_above_threshold"] > 0
+        assert {k_.split("P=")[1].split(",")[0] for k_ in g["fetch_all_rows"]["scan_launches"]} == {"10", "13"}
+        assert 0 < g["fetch_all_rows"]["roofline"]["frac"] < 1.0
     # the device-tensor gather path of the RCCL runs (D2D copy of the ordered records, read-back), one rank
     forced = tmp_path / "forced.npy"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(forced), "--no-clustered"],
@@ -229,15 +251,19 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     assert np.array_equal(np.load(one), np.load(forced))
     two = tmp_path / "two.npy"
     env2 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    # every N > 1 line is self-sufficient: the CPU path is timed in the same run (rank 0, the other rank sleeps on a store
+    # key), `roofline` is there with `traffic` null AND the reason, the ranks are counted
+    small_cpu = [a_ for a_ in common if a_ != "--no-cpu-baseline"] + ["--cpu-target-s", "0.6", "--cpu-sample-gb", "0.2"]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--clustered-multi"] + common + ["--dump-hits", str(two)], capture_output=True, env=env2)
+                        "--gpus", "2", "--clustered-multi"] + small_cpu + ["--dump-hits", str(two)], capture_output=True, env=env2)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     a, b = np.load(one), np.load(two)
     assert len(a) > 50 and np.array_equal(a, b)
     line2 = json.loads(r.stdout.decode().strip().splitlines()[-1])
     part = line2["participants"]
     assert part["ranks"] == 2 and len(part["rank_ms_per_step"]) == 2 and part["rank_devices"] == [0, 0]
+    _check_multi_rank_line(line2, 2)
     assert sum(part["rank_batches"]) == 64 and min(part["rank_batches"]) >= 1
     assert abs(max(part["rank_ms_per_step"]) - line2["ms_per_step"]) < 1e-6          # the job's step is the slowest rank's
     # BASELINE configs[3]: with 8 ranks (here: 2, forced) all 305 batches are sharded over the ranks and searched with
@@ -457,12 +483,14 @@ def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     eight, fullc = tmp_path / "eight.npy", tmp_path / "fullc.npy"
     env8 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_FULL_MIN_WORLD="8")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--replicas"] + common +
+    small_cpu = [a_ for a_ in common if a_ != "--no-cpu-baseline"] + ["--cpu-target-s", "0.6", "--cpu-sample-gb", "0.2"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--replicas"] + small_cpu +
                        ["--dump-hits", str(eight), "--dump-full-hits", str(fullc)], capture_output=True, env=env8)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                       # ONE JSON line, from rank 0
     line = json.loads(lines[0])
+    _check_multi_rank_line(line, 8)
     part = line["participants"]
     assert line["n_gpus"] == 8 and part["ranks"] == 8 and len(part["rank_ms_per_step"]) == 8 and len(part["rank_host_ms"]) == 8
     shared = line["config"]["batches_on_two_ranks"]

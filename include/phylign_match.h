@@ -134,6 +134,9 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * "single_launch" (default 0): rows of every width up to 1024 B share one launch.
  * "merge_counting_sort" (default 1): hit lists written as several runs (rows wider than 1024 B, compact sub-indexes) are
  * merged by a counting sort on the score; 0 = the general pairwise form for every group (same result).
+ * "release_query_pool" (any value; an action): the device buffers of query sets that gave their HBM copies back
+ * (pm_queries_release_device) wait in a small pool for the next set -- freeing them on the spot would wait for every
+ * search queued behind -- and this call really frees them (it waits for the device: call it between jobs).
  * "cobs_threshold_rule" (default 0) / "cobs_tie_order" (default 0): the two rules of `cobs query` that no file of the
  * reference pins -- how -t becomes a minimum score: 0 = ceil(t x k-mers), 1 = floor, 2 = round half up; how documents of
  * equal score are listed: 0 = ascending document index, 1 = descending.  The defaults are upstream's as recalled

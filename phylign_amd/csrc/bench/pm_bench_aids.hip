@@ -483,9 +483,9 @@ extern "C" int pm_bench_unique_rows(const pm_index_t* ix, const pm_bench_hashes_
                      h->canon, h->nh, info.canonicalize, info.num_hashes);
     const uint64_t S = info.signature_size, n_words = (S + 31) / 32, n = h->n_terms * h->nh;
     uint32_t* bitmap = nullptr; unsigned long long* d_out = nullptr;
-    BHIP(hipMalloc((void**)&bitmap, n_words * 4 + 8));
+    BHIP(hipMalloc((void**)&bitmap, n_words * 4 + 16));        // + the 8-byte counter, 8-byte aligned behind the bitmap
     d_out = reinterpret_cast<unsigned long long*>(bitmap + ((n_words + 1) & ~1ull));
-    hipError_t e = hipMemsetAsync(bitmap, 0, n_words * 4 + 8, nullptr);
+    hipError_t e = hipMemsetAsync(bitmap, 0, n_words * 4 + 16, nullptr);
     if (e == hipSuccess && n) {
         hipLaunchKernelGGL(k_mark_rows, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536)), dim3(256), 0, nullptr,
                            bitmap, h->d_hashes, n, S, barrett_m(S));

@@ -221,7 +221,7 @@ def split_prepared_fasta(fasta, max_records, piece_bytes=0):
 
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
               want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31,
-              query_reserve_bytes=0):
+              query_reserve_bytes=0, write_match_files=True):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
     `batches`).  `queries` is one pm.Queries or a LIST of them (or of Futures of them: a file that is still being parsed):
     the chunks, in file order, of a query file with more reads than fit HBM at once, or of one cut up so that parsing and
@@ -341,7 +341,12 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
         def one_batch(i, b, ix, part):
             path = os.path.join(out_dir, f"{b}____{qfile}.gz")
             ta = time.perf_counter()
-            if keep_texts is None:
+            if not write_match_files:
+                # --filter-only: the 04_filter FASTA is all that is wanted; the per-batch files (what makes the reference's
+                # stage resumable, Snakefile:490-520) are not written, the records go straight into the merge
+                text = None
+                tb = tc = tc0 = time.perf_counter()
+            elif keep_texts is None:
                 # records -> post-filtered text -> `gzip --fast` members -> file, all inside the library (Snakefile:463-469)
                 pm.format_hits_gz(ix, qc, part, path, slot=i, nb_best_hits=nb, level=1, piece=piece)
                 text = None
@@ -420,6 +425,8 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             raise
     workers.shutdown()
     deflaters.shutdown()
+    if nc > 1:
+        pm.set_option("release_query_pool", 1)     # the chunks' pooled device buffers: nothing is queued any more, really free them
     nq = sum(chunk(ci).count()[0] for ci in range(nc))
     n_terms = sum(chunk(ci).count()[1] for ci in range(nc))
     report = {"batches": len(mine), "queries": nq, "kmers": n_terms, "query_chunks": nc, "groups": len(group_rows),
@@ -550,6 +557,10 @@ def main(argv=None):
     ap.add_argument("--threshold", type=float, default=0.7)          # config.yaml:20
     ap.add_argument("--nb-best-hits", type=int, default=100)         # config.yaml:23
     ap.add_argument("--filter-out", default=None)
+    ap.add_argument("--filter-only", action="store_true",
+                    help="with --filter-out: do not write the per-batch intermediate/03_match/*.gz files, only the 04_filter FASTA "
+                         "(the records go from the GPU straight into the merge).  Off by default: the files are what makes the "
+                         "reference's pipeline resumable and what its rule translate_matches reads (Snakefile:490-520)")
     ap.add_argument("--loaders", type=int, default=0,
                     help="concurrent xz decoders per rank (0 = the CPUs the job may use minus 4, at least 4, at most 16 -- one "
                          "xz stream decodes 0.1-0.2 GB/s on one core, and decoding is what a cold stage waits for -- and no "
@@ -595,6 +606,8 @@ def main(argv=None):
         apply_reference_config(args, ap)
     if not args.out_dir:
         ap.error("--out-dir is required (or --config)")
+    if args.filter_only and not args.filter_out and not args.config:
+        ap.error("--filter-only needs --filter-out")
     from . import launch
     if not args.queries and not args.input_dir:
         ap.error("--queries or --input-dir is required")
@@ -703,7 +716,7 @@ def main(argv=None):
         host_ram = source.host_ram = sizing.HostRam(budget_mb)
         source.host_mb = host_mb
     report, merge = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
-                              want_merge=bool(args.filter_out), loaders=args.loaders, budget_bytes=budget,
+                              want_merge=bool(args.filter_out), write_match_files=not args.filter_only, loaders=args.loaders, budget_bytes=budget,
                               max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve)
     parser.shutdown()
     del fasta

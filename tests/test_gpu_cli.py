@@ -179,6 +179,25 @@ def _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, n):
     assert not list((tmp_path / "03_match").glob("*.tmp"))
 
 
+def test_match_stage_filter_only_writes_the_same_fasta_and_no_match_files(pm, oracle, tmp_path):
+    """--filter-only (opt-in): the records go from the GPU straight into the 04_filter merge, no per-batch .gz is written;
+    the FASTA is byte for byte the default run's (which the other tests pin against the reference's filter_queries.py)"""
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"), "--cobs-dir", str(tmp_path / "cobs"),
+            "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"), "--nb-best-hits", "3"]
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_match"), "--filter-out", str(tmp_path / "04_filter" / "Q.fa")], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_only"), "--filter-out", str(tmp_path / "04_only" / "Q.fa"), "--filter-only"],
+                       capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert (tmp_path / "04_only" / "Q.fa").read_bytes() == (tmp_path / "04_filter" / "Q.fa").read_bytes()
+    assert not list((tmp_path / "03_only").glob("*"))
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_x"), "--filter-only"], capture_output=True, env=env)
+    assert r.returncode == 2 and b"--filter-only needs --filter-out" in r.stderr
+
+
 @pytest.mark.parametrize("n", [3, 100])
 def test_match_stage_end_to_end_single_rank(pm, oracle, tmp_path, n):
     names, indexes, fasta = _stage_fixture(oracle, tmp_path)
@@ -596,6 +615,7 @@ def test_query_chunks_do_not_accumulate_in_hbm(pm, oracle, tmp_path):
             assert per_chunk[0][0] == per_chunk[0][1] > 60 << 20
             chunks[0].release_device()
             assert chunks[0].device_bytes()[0] == 0
+        pm.set_option("release_query_pool", 1)                       # released copies wait in a bounded pool: really free them
         free_after[nchunks] = pm.device_info()["hbm_free"]
         # a released set is searched again like a fresh one
         a = pm.search([src.indexes[batches[0]]], chunks[-1], 0.7).hits()

@@ -439,7 +439,7 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
     """several narrow batches of different lane-group widths (one mixed-width launch) x queries of
     every counter-width class, plus a wide and a column-slab batch, in ONE search"""
     rng = np.random.default_rng(77)
-    lens = [31, 37, 38, 150, 150, 158, 159, 400, 1054, 1055, 3000, 65566, 150, 40]
+    lens = [31, 37, 38, 150, 150, 158, 159, 400, 1054, 1055, 3000, 8221, 8222, 65566, 150, 40]
     queries = [(f"w{i}", rand_seq(rng, n)) for i, n in enumerate(lens)]
     shapes = [(13, 900), (100, 700), (200, 800), (300, 600), (664, 900), (1500, 500), (4000, 400), (9001, 300), (50, 1000)]
     cases = []
@@ -454,7 +454,7 @@ def test_mixed_width_launch_with_every_counter_class(pm, oracle):
         res = pm.search(ixs, q, thr, slot_base=5)
         kernels = [L["kernel"] for L in res.launches()]
         assert any("G=mixed" in k for k in kernels) and any("G=32" in k for k in kernels)
-        assert {k.split("P=")[1].split(",")[0] for k in kernels} == {"3", "7", "10", "16", "20"}
+        assert {k.split("P=")[1].split(",")[0] for k in kernels} == {"3", "7", "10", "13", "16", "20"}
         hits = res.hits()
         for s, (index, _, _) in enumerate(cases):
             assert pm.format_hits(ixs[s], q, hits, slot=5 + s) == oracle.query_file(index, fasta, thr), shapes[s]

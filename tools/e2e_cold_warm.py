@@ -56,7 +56,15 @@ def main():
     ap.add_argument("--work", default="/tmp/phylign_cold_warm")
     ap.add_argument("--out", default=None)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--modes", default="cold,cached,resident",
+                    help="comma list of cold (xz -> HBM, fills the cache), cached (second run on the decode-once cache), plain "
+                         "(decompressed .cobs_classic files in --cobs-dir: rule decompress_cobs / mem-disk, no .xz involved), resident.  "
+                         "Without `cold` no .xz is made and the cache directory is filled by MOVING the plain files into it "
+                         "(what a cold run leaves there): the full-size shard (--rows-divisor 1, 128 GB) fits a memory-backed --work "
+                         "only once")
     args = ap.parse_args()
+    modes = [m for m in args.modes.split(",") if m]
+    assert set(modes) <= {"cold", "cached", "plain", "resident"} and modes
 
     shutil.rmtree(args.work, ignore_errors=True)
     os.makedirs(os.path.join(args.work, "cobs"))
@@ -88,62 +96,84 @@ def main():
             sz.write(f"cobs/{s.batch}.cobs_classic.xz  {n}  1610678320\n")
             bl.write(s.batch + "\n")
     t_save = time.perf_counter() - t0
-    t0 = time.perf_counter()
     files = [os.path.join(args.work, "cobs", f"{s.batch}.cobs_classic") for s in sub]
-    subprocess.run(["xz", "-T0", args.xz_level, "--block-size=16MiB"] + files, check=True)
-    t_xz = time.perf_counter() - t0
-    xz_bytes = sum(os.path.getsize(f + ".xz") for f in files)
-    print(f"[cold_warm] {len(sub)} batches, {plain_bytes / 1e9:.2f} GB plain, {xz_bytes / 1e9:.2f} GB as .xz "
-          f"(saved in {t_save:.1f} s, xz {args.xz_level} in {t_xz:.1f} s)", file=sys.stderr, flush=True)
     q.free()
     pm.shutdown()                                            # the stage runs are processes of their own
-
     cache = os.path.join(args.work, "cache")
     rows = {}
-    for name in ("cold", "cached"):
+
+    def stage_row(name, extra):
         out_dir = os.path.join(args.work, f"03_{name}")
-        wall, rep = run_stage_cmd(stage_cmd(args.work, out_dir, os.path.join(args.work, f"04_{name}", "Q.fa"), ["--cache-dir", cache]))
+        wall, rep = run_stage_cmd(stage_cmd(args.work, out_dir, os.path.join(args.work, f"04_{name}", "Q.fa"), extra))
         rows[name] = {"process_wall_s": round(wall, 3), "e2e_s": rep["e2e_s"], "stage_wall_s": rep["stage_wall_s"],
                       "match_only_s": rep["match_only_s"], "load_s_thread_sum": rep["load_s_thread_sum"],
-                      "index_source": rep["index_source"], "host_ram_plan": rep["host_ram_plan"], "groups": rep["groups"]}
-    same = all(open(os.path.join(args.work, "03_cold", f), "rb").read() == open(os.path.join(args.work, "03_cached", f), "rb").read()
-               for f in os.listdir(os.path.join(args.work, "03_cold")))
-    same = same and open(os.path.join(args.work, "04_cold", "Q.fa"), "rb").read() == open(os.path.join(args.work, "04_cached", "Q.fa"), "rb").read()
+                      "index_source": rep["index_source"], "host_ram_plan": rep["host_ram_plan"], "groups": rep["groups"],
+                      "index_GBps_over_e2e": plain_bytes / rep["e2e_s"] / 1e9, "index_GBps_over_process_wall": plain_bytes / wall / 1e9}
+    if "plain" in modes:                                     # decompressed files in --cobs-dir: before any .xz exists
+        stage_row("plain", [])
+    xz_bytes, t_xz = 0, 0.0
+    if "cold" in modes:
+        t0 = time.perf_counter()
+        subprocess.run(["xz", "-T0", args.xz_level, "--block-size=16MiB"] + files, check=True)
+        t_xz = time.perf_counter() - t0
+        xz_bytes = sum(os.path.getsize(f + ".xz") for f in files)
+        # the block structure the decoder would see (`xz --list`): blocks per file decide whether a file could be decoded
+        # by several threads at all
+        lst = subprocess.run(["xz", "--robot", "--list"] + [f + ".xz" for f in files], capture_output=True, text=True).stdout
+        blocks = [int(ln.split("\t")[2]) for ln in lst.splitlines() if ln.startswith("file\t")]
+        rows["xz_list"] = {"files": len(blocks), "blocks_min": min(blocks), "blocks_max": max(blocks), "blocks_total": sum(blocks)}
+        stage_row("cold", ["--cache-dir", cache])
+    else:
+        os.makedirs(cache, exist_ok=True)
+        for f in files:                                      # what a cold run leaves in the cache: the decoded files
+            os.rename(f, os.path.join(cache, os.path.basename(f)))
+    print(f"[cold_warm] {len(sub)} batches, {plain_bytes / 1e9:.2f} GB plain, {xz_bytes / 1e9:.2f} GB as .xz "
+          f"(saved in {t_save:.1f} s = {plain_bytes / t_save / 1e9:.2f} GB/s, xz {args.xz_level} in {t_xz:.1f} s)", file=sys.stderr, flush=True)
+    if "cached" in modes:
+        stage_row("cached", ["--cache-dir", cache])
+    first = [m for m in ("plain", "cold", "cached") if m in rows][0]
+
+    def same_as_first(name):
+        a, b = os.path.join(args.work, f"03_{first}"), os.path.join(args.work, f"03_{name}")
+        ok_ = all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in os.listdir(a))
+        return ok_ and open(os.path.join(args.work, f"04_{first}", "Q.fa"), "rb").read() == open(os.path.join(args.work, f"04_{name}", "Q.fa"), "rb").read()
+    same = all(same_as_first(m) for m in ("plain", "cold", "cached") if m in rows and m != first)
 
     # ---- resident: the matrices stay in HBM between query sets (server); in-process, load time outside the timer
-    pm.init(0)
-    t0 = time.perf_counter()
-    ixs = {s.batch: pm.Index.load_file(os.path.join(cache, f"{s.batch}.cobs_classic")) for s in sub}
-    t_load = time.perf_counter() - t0
-    names = sorted(ixs)
-    src = MS.ResidentSource(ixs)
-    res_rows = []
-    for _ in range(2):                                       # first pass warms the pooled buffers
+    if "resident" in modes:
+        pm.init(0)
         t0 = time.perf_counter()
-        qq = pm.Queries(fasta)
-        rep, merge = MS.run_stage(pm, names, list(range(len(names))), src, qq, "Q", os.path.join(args.work, "03_resident"), 0.7, 100,
-                                  want_merge=True)
-        os.makedirs(os.path.join(args.work, "04_resident"), exist_ok=True)
-        merge.emit_to(os.path.join(args.work, "04_resident", "Q.fa"))
-        res_rows.append(time.perf_counter() - t0)
-        merge.free()
-        qq.free()
-    same = same and all(open(os.path.join(args.work, "03_cold", f), "rb").read() == open(os.path.join(args.work, "03_resident", f), "rb").read()
-                        for f in os.listdir(os.path.join(args.work, "03_cold")))
-    same = same and open(os.path.join(args.work, "04_cold", "Q.fa"), "rb").read() == open(os.path.join(args.work, "04_resident", "Q.fa"), "rb").read()
-    rows["resident"] = {"e2e_s": round(res_rows[-1], 3), "match_only_s": rep["match_only_s"],
-                        "plain_files_to_hbm_s": round(t_load, 3), "plain_files_to_hbm_GBps": plain_bytes / t_load / 1e9}
+        ixs = {s.batch: pm.Index.load_file(os.path.join(cache, f"{s.batch}.cobs_classic")) for s in sub}
+        t_load = time.perf_counter() - t0
+        names = sorted(ixs)
+        src = MS.ResidentSource(ixs)
+        res_rows = []
+        for _ in range(2):                                       # first pass warms the pooled buffers
+            t0 = time.perf_counter()
+            qq = pm.Queries(fasta)
+            rep, merge = MS.run_stage(pm, names, list(range(len(names))), src, qq, "Q", os.path.join(args.work, "03_resident"), 0.7, 100,
+                                      want_merge=True)
+            os.makedirs(os.path.join(args.work, "04_resident"), exist_ok=True)
+            merge.emit_to(os.path.join(args.work, "04_resident", "Q.fa"))
+            res_rows.append(time.perf_counter() - t0)
+            merge.free()
+            qq.free()
+        same = same and same_as_first("resident")
+        rows["resident"] = {"e2e_s": round(res_rows[-1], 3), "match_only_s": rep["match_only_s"],
+                            "plain_files_to_hbm_s_one_thread_of_loads": round(t_load, 3), "plain_files_to_hbm_GBps": plain_bytes / t_load / 1e9}
     line = {
         "config": f"rank {args.rank} of {args.world} of batches_full.txt with rows / {args.rows_divisor}: {len(sub)} batches, "
                   f"{plain_bytes / 1e9:.2f} GB of index files ({xz_bytes / 1e9:.2f} GB as .xz), {args.queries} x {args.qlen} bp queries, "
-                  f"threshold 0.7, nb_best_hits 100, 03_match files + 04_filter FASTA",
-        "cold_s": rows["cold"]["e2e_s"], "cached_s": rows["cached"]["e2e_s"], "resident_s": rows["resident"]["e2e_s"],
-        "cold_decode_GBps": plain_bytes / rows["cold"]["e2e_s"] / 1e9, "cached_load_GBps": plain_bytes / rows["cached"]["e2e_s"] / 1e9,
+                  f"threshold 0.7, nb_best_hits 100, 03_match files + 04_filter FASTA; files under {args.work}",
+        "index_GB": plain_bytes / 1e9,
         "outputs_identical": bool(same), "planted_pairs_at_or_above_threshold": sure,
         "host_cpus": len(os.sched_getaffinity(0)), "runs": rows,
         "note": "synthetic Bernoulli(1/4) signatures barely compress: the .xz decode is slower per output byte than on the real "
-                "661k indexes; cold_s is conservative",
+                "661k indexes; a cold figure is conservative",
     }
+    for m in ("plain", "cold", "cached", "resident"):
+        if m in rows:
+            line[m + "_s"] = rows[m]["e2e_s"]
     print(json.dumps(line), flush=True)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

@@ -41,6 +41,8 @@ def main():
                     help="> 0: the query file is cut into pieces of about this many MB that are parsed by a thread of their own "
                          "INSIDE the timed stage (match_stage's default, 48): parsing overlaps the searches of earlier pieces")
     ap.add_argument("--out", default="gpurun_out/e2e")
+    ap.add_argument("--filter-only", action="store_true", help="match_stage --filter-only: no per-batch .gz files, only the 04_filter FASTA")
+    ap.add_argument("--json", default=None, help="append the JSON lines to this file")
     args = ap.parse_args()
 
     pm.init(0)
@@ -97,7 +99,7 @@ def main():
                 parser = ThreadPoolExecutor(max_workers=1)
                 stage_q = [parser.submit(parse_piece, p_) for p_ in MS.split_prepared_fasta(fasta, args.query_chunk, args.piece_mb << 20)]
             report, merge = MS.run_stage(pm, names, list(range(len(names))), src, stage_q, "Q", out_dir, args.threshold,
-                                          args.nb_best_hits, want_merge=True, max_group=mg)
+                                          args.nb_best_hits, want_merge=True, max_group=mg, write_match_files=not args.filter_only)
             if args.piece_mb > 0:
                 parser.shutdown()
             t1 = time.perf_counter()
@@ -110,7 +112,7 @@ def main():
                     f_.result().free()
             if warm and args.queries > 200_000:
                 break                            # one pass is enough at 1 M queries (the pools matter little there)
-        gz = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+        gz = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir)) if os.path.isdir(out_dir) else 0
         line = {
             "config": f"{args.workload} shard {args.rank}/{args.world}: {len(sub)} batches, {resident / 1e9:.1f} GB resident, "
                       f"{alg_per_kmer} row bytes per k-mer; {nq} x {args.qlen} bp queries, threshold {args.threshold}, "
@@ -129,8 +131,12 @@ def main():
             "e2e_kmers_per_s": n_terms / ((0.0 if args.piece_mb > 0 else t_parse) + (t2 - t0)),
             "records": sum(g["records"] for g in report["per_group"]),
             "gz_bytes": gz, "filter_fasta_bytes": fasta_bytes, "host_cpus": len(os.sched_getaffinity(0)),
+            "filter_only": args.filter_only,
         }
         print(json.dumps(line), flush=True)
+        if args.json:
+            with open(args.json, "a") as f:
+                f.write(json.dumps(line) + "\n")
 
 
 if __name__ == "__main__":

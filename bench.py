@@ -446,13 +446,13 @@ def main():
         kernel source they were measured on (git blob of pm_kernels.hip), this workload and this query count"""
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
-            tj = json.load(open(tpath))
-            if tj.get("pm_kernels_blob") != blob:
-                return None, f"profiles/pmc_traffic.json was measured on pm_kernels.hip blob {str(tj.get('pm_kernels_blob'))[:12]}, this is {blob[:12]}: re-run tools/run_pmc.sh"
             if world > 1 or args.emulate_world:
                 return None, (f"the PMC passes (profiles/pmc_traffic.json) were collected on the 1-rank launch that covers all "
                               f"{len(shapes)} batches; a rank of {nparts} launches over its own shard only, so the per-launch figure "
                               "does not transfer (1-rank ratio traffic / algorithmic: see the N = 1 line)")
+            tj = json.load(open(tpath))
+            if tj.get("pm_kernels_blob") != blob:
+                return None, f"profiles/pmc_traffic.json was measured on pm_kernels.hip blob {str(tj.get('pm_kernels_blob'))[:12]}, this is {blob[:12]}: re-run tools/run_pmc.sh"
             if tj.get("workload") == cur["tag"] and tj.get("queries") == args.queries and args.rows_divisor == 1 \
                     and args.qlen == tj.get("query_len", 150):
                 ent = tj.get("kernels", {}).get(name, {}).get(mode)

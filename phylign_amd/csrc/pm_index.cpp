@@ -1,6 +1,7 @@
 // pm_index.cpp -- index residency: COBS classic / compact header
 // readers, streaming upload with re-striding, synthetic 661k-shaped indexes, planted content.
 #include "pm_host.h"
+#include <chrono>
 
 // ---------------------------------------------------- classic index header
 // "COBS:" "CLASSIC_INDEX" u32 version, then the fields, the newline-terminated
@@ -106,7 +107,11 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     uint64_t lanes = (std::min<uint64_t>(stride, 1024) + 15) / 16;
     ix->g = (int)pow2ceil(lanes);
     ix->slabs = (uint32_t)((stride + 1023) / 1024);
+    const auto t_m0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void**)&ix->d_matrix, in.device_bytes);
+    if (getenv("PM_LOAD_TRACE"))
+        fprintf(stderr, "[pm_load] hipMalloc %.2f GB: %.1f ms\n", in.device_bytes / 1e9,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_m0).count());
     if (e != hipSuccess || !ix->d_matrix) {
         ix->d_matrix = nullptr;
         return fail(PM_ENOMEM, "hipMalloc(%llu bytes) for the signature matrix failed: %s",
@@ -282,6 +287,11 @@ static int stream_matrix_file(int fd, uint64_t file_off, pm_index* ix, uint64_t 
     std::vector<int> rcs((size_t)nthreads, PM_OK);
     std::vector<std::string> errs((size_t)nthreads);
     const int device = g_ctx.device;
+    // PM_LOAD_TRACE: where a load spends its time -- pread out of the page cache vs waiting for the staging buffer's H2D
+    const bool trace = getenv("PM_LOAD_TRACE") != nullptr;
+    std::vector<double> t_read((size_t)nthreads, 0.0), t_wait((size_t)nthreads, 0.0);
+    const auto t_all0 = std::chrono::steady_clock::now();
+    auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     auto worker = [&](int t) {
         char msg[256];
         hipError_t e = hipSetDevice(device);
@@ -292,7 +302,9 @@ static int stream_matrix_file(int fd, uint64_t file_off, pm_index* ix, uint64_t 
         for (uint64_t c = (uint64_t)t; c < n_chunks && e == hipSuccess && rcs[(size_t)t] == PM_OK; c += (uint64_t)nthreads) {
             const uint64_t row = c * chunk_rows, nrows = std::min<uint64_t>(chunk_rows, S - row);
             const size_t nbytes = (size_t)(nrows * rb);
+            auto t0 = std::chrono::steady_clock::now();
             if (used[cur]) { e = hipEventSynchronize(sg.ev[cur]); if (e != hipSuccess) break; }
+            if (trace) { t_wait[(size_t)t] += secs(t0); t0 = std::chrono::steady_clock::now(); }
             size_t got = 0;
             while (got < nbytes) {
                 ssize_t r = pread(fd, sg.hbuf[cur] + got, nbytes - got, (off_t)(file_off + row * rb + got));
@@ -300,6 +312,7 @@ static int stream_matrix_file(int fd, uint64_t file_off, pm_index* ix, uint64_t 
                 if (r == 0) break;
                 got += (size_t)r;
             }
+            if (trace) t_read[(size_t)t] += secs(t0);
             if (got != nbytes) {
                 snprintf(msg, sizeof msg, "index file ended after %llu of %llu matrix bytes",
                          (unsigned long long)(row * rb + got), (unsigned long long)(S * rb));
@@ -324,6 +337,13 @@ static int stream_matrix_file(int fd, uint64_t file_off, pm_index* ix, uint64_t 
     for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
     worker(0);
     for (auto& x : th) x.join();
+    if (trace) {
+        double r = 0, w = 0;
+        for (int t = 0; t < nthreads; ++t) { r += t_read[(size_t)t]; w += t_wait[(size_t)t]; }
+        const double wall = secs(t_all0);
+        fprintf(stderr, "[pm_load] %.2f GB in %.3f s = %.1f GB/s; %d readers: pread %.3f s, waiting for a staging buffer %.3f s (mean per reader)\n",
+                S * rb / 1e9, wall, S * rb / 1e9 / wall, nthreads, r / nthreads, w / nthreads);
+    }
     for (int t = 0; t < nthreads; ++t)
         if (rcs[(size_t)t] != PM_OK) return fail(rcs[(size_t)t], "%s", errs[(size_t)t].c_str());
     return PM_OK;

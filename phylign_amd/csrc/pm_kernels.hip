@@ -267,6 +267,9 @@ __device__ __forceinline__ u32x4 ld_row(const uint8_t* p) {
 #ifndef PM_SCAN_WAVES_P20
 #define PM_SCAN_WAVES_P20 3
 #endif
+#ifndef PM_SCAN_WAVES_P20_WQ
+#define PM_SCAN_WAVES_P20_WQ 3
+#endif
 #ifndef PM_SCAN_WAVES_P24
 #define PM_SCAN_WAVES_P24 2
 #endif
@@ -279,7 +282,7 @@ __device__ __forceinline__ u32x4 ld_row(const uint8_t* p) {
 // is off in this form (partial counts say nothing about a document's total); group 0 of the
 // query runs the usual epilogue on the combined planes.  Results are identical to the plain form.
 template <int G, int P, bool NH1, bool WQ>
-__global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : (P <= 20 ? PM_SCAN_WAVES_P20 : PM_SCAN_WAVES_P24)))) void k_scan(const ScanArgs a)
+__global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ ? PM_SCAN_WAVES_P16_WQ : PM_SCAN_WAVES_P16) : (P <= 20 ? (WQ ? PM_SCAN_WAVES_P20_WQ : PM_SCAN_WAVES_P20) : PM_SCAN_WAVES_P24)))) void k_scan(const ScanArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

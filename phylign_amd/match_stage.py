@@ -106,6 +106,25 @@ def open_index_stream(cobs_dir, batch, cache_dir=None):
     return p.stdout, p
 
 
+def xz_block_structure(paths):
+    """`xz --robot --list` of the given .xz files (it reads only the stream footers and indexes): how many blocks each
+    file holds.  One block (what plain `xz` writes, and what the reference's own data/*.xz are) can only be decoded by one
+    thread; a multi-block file (`xz -T`) could be decoded by several.  The stage decodes one file per loader thread
+    either way -- the image's xz 5.2.5 has no threaded decoder -- and reports what it saw, so that a run on the real
+    661k indexes says whether in-file threading would have anything to work with.  None when xz cannot tell."""
+    paths = [p_ for p_ in paths if os.path.exists(p_)]
+    if not paths:
+        return None
+    try:
+        out = subprocess.run(["xz", "--robot", "--list"] + paths, capture_output=True, text=True, timeout=120)
+        blocks = [int(ln.split("\t")[2]) for ln in out.stdout.splitlines() if ln.startswith("file\t")]
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        return None
+    if len(blocks) != len(paths):
+        return None
+    return {"files": len(blocks), "multi_block_files": sum(1 for b in blocks if b > 1), "blocks_max": max(blocks), "blocks_total": sum(blocks)}
+
+
 class FileSource:
     """indexes read from <cobs-dir>/<batch>.cobs_classic[.xz] (what the reference's rules read).
 
@@ -120,6 +139,10 @@ class FileSource:
         self.host_ram, self.host_mb = host_ram, host_mb or {}
         self.counts = {"xz_decoded": 0, "plain_files": 0, "cache_files_written": 0}
         self._mu = threading.Lock()
+        # plain files are read by the library's own pread workers (6 per file, PM_LOAD_THREADS), which move 40+ GB/s out of
+        # the page cache by themselves: the loader threads -- as many as xz decoders would need, sizing.stage_plan -- take
+        # turns at them, or 12 x 6 copy threads share the job's CPUs (measured on a 128 GB shard: profiles/r05/NOTES.md)
+        self._plain_gate = threading.Semaphore(max(1, int(os.environ.get("PHYLIGN_PLAIN_LOADS", "2"))))
         if cache_dir:
             os.makedirs(cache_dir, exist_ok=True)
 
@@ -141,7 +164,11 @@ class FileSource:
             tee = os.path.join(self.cache_dir, f"{batch}.cobs_classic") if (self.cache_dir and proc is not None) else None
             ix = None
             try:
-                ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0), tee_path=tee)
+                if proc is None:
+                    with self._plain_gate:
+                        ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0), tee_path=tee)
+                else:
+                    ix = self.pm.Index.load_fd(fobj.fileno(), size_hint=self.sizes.get(batch, 0), tee_path=tee)
             finally:
                 fobj.close()
                 if proc is not None and proc.wait() != 0:
@@ -375,6 +402,9 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             # no hipFree -- which would wait for that queued scan -- is involved.
             qc.release_device()
         if ci == nc - 1:                                 # the group has seen every chunk: its matrices may go
+            # (freed on the spot.  Keeping them until the end of the stage -- hipFree waits for the device -- was measured on
+            # a 128 GB shard and is no faster; a process that exits holding its whole shard leaves the driver 135 GB of HBM
+            # to scrub, which the next process's first large hipMalloc then waits 2.5 - 3.5 s for: profiles/r05/NOTES.md)
             for pos, ix, held in group:
                 if not resident:
                     ix.free()
@@ -720,6 +750,9 @@ def main(argv=None):
                               max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve)
     parser.shutdown()
     del fasta
+    if isinstance(source, FileSource) and report["index_source"].get("xz_decoded"):
+        report["index_source"]["xz_blocks"] = xz_block_structure(
+            [os.path.join(source.cobs_dir, f"{batches[pos]}.cobs_classic.xz") for pos in mine])
 
     # ---- 04_filter: ONE gather of what every rank's merge kept (queries numbered through the whole file, slot = the
     # batch's number in that rank's merge), rank 0 adds the parts and emits

@@ -648,6 +648,8 @@ def test_match_stage_decode_once_cache(pm, oracle, tmp_path):
                            capture_output=True, env=env)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         reports.append(json.loads([ln for ln in r.stderr.decode().splitlines() if ln.startswith("{")][-1]))
+    # the block structure of the .xz files that were decoded (`xz --list`): python's lzma writes one block per file
+    assert reports[0]["index_source"].pop("xz_blocks") == {"files": 5, "multi_block_files": 0, "blocks_max": 1, "blocks_total": 5}
     assert reports[0]["index_source"] == {"xz_decoded": 5, "plain_files": 0, "cache_files_written": 5, "resident": 0}
     assert reports[1]["index_source"] == {"xz_decoded": 0, "plain_files": 5, "cache_files_written": 0, "resident": 0}
     assert reports[2]["index_source"] == reports[1]["index_source"]
@@ -672,3 +674,41 @@ def test_match_stage_decode_once_cache(pm, oracle, tmp_path):
     r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_match_x"), "--cache-dir", str(cache)], capture_output=True, env=env)
     assert r.returncode != 0
     assert not (cache / f"{broken}.cobs_classic").exists() and not list(cache.glob("*.tmp"))
+
+
+def test_two_decoders_of_one_batch_share_a_cache_directory(pm, oracle, tmp_path):
+    """two loads of the same uncached batch into the same cache path at once (two stage runs, or stage and
+    server): each writes a temporary of its own, the published file is complete whichever finishes first, nothing else is
+    left behind, and both indexes are the resident index"""
+    import threading
+    rng = np.random.default_rng(3)
+    index, fasta, _ = build_case(oracle, rng, 664, 150000, [("q", rand_seq(rng, 150))])     # 12 MB through paced pipes: the two loads overlap
+    blob = bytes(index)
+    tee = str(tmp_path / "b__01.cobs_classic")
+    out, errs = [None, None], []
+
+    def loader(i):
+        try:
+            r, w = os.pipe()
+
+            def feed():
+                with os.fdopen(w, "wb") as f:
+                    for o in range(0, len(blob), 1 << 16):
+                        f.write(blob[o:o + (1 << 16)])
+            t = threading.Thread(target=feed)
+            t.start()
+            try:
+                out[i] = pm.Index.load_fd(r, size_hint=len(blob), tee_path=tee)
+            finally:
+                os.close(r)
+                t.join()
+        except Exception as e:                              # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=loader, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and all(ix is not None and ix.cached for ix in out)
+    assert sorted(f.name for f in tmp_path.iterdir()) == ["b__01.cobs_classic"]
+    assert open(tee, "rb").read() == blob
+    for ix in out:
+        assert pm.query_text(ix, fasta, 0.7) == oracle.query_file(index, fasta, 0.7)

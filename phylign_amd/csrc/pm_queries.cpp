@@ -67,7 +67,8 @@ static int finish_queries(pm_queries* q) {
             else if (q->n_terms[i] != first_nt) mixed = true;
             q->qmap.push_back((uint32_t)i);
         }
-        if (mixed)
+        static const bool sort_on = !(getenv("PM_QMAP_SORT") && atoi(getenv("PM_QMAP_SORT")) == 0);   // 0: file order (for the A/B)
+        if (mixed && sort_on)
             std::stable_sort(q->qmap.begin() + q->class_begin[c], q->qmap.end(),
                              [&](uint32_t x, uint32_t y) { return q->n_terms[x] > q->n_terms[y]; });
     }

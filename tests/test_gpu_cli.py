@@ -712,3 +712,35 @@ def test_two_decoders_of_one_batch_share_a_cache_directory(pm, oracle, tmp_path)
     assert open(tee, "rb").read() == blob
     for ix in out:
         assert pm.query_text(ix, fasta, 0.7) == oracle.query_file(index, fasta, 0.7)
+
+
+def test_match_stage_with_gene_length_queries(pm, oracle, tmp_path):
+    """the reference's bundled gene file as a query set: every 8th record length of data/ARGannot_r3.fa
+    (232 genes, 237 ... 3 150 bp: the 10- and 13-plane counter classes in one search) through the whole stage -- .xz
+    indexes, fused post-filter, gzip members, 04_filter merge -- against the oracle and the golden-pinned mirrors"""
+    from phylign_amd import workload as W
+    lens = W.argannot_lengths()[::8]
+    fasta, seqs = W.make_queries_lengths(lens, seed=5, prefix="ARG")
+    queries = [(f"ARG{i:07d}", s_.decode()) for i, s_ in enumerate(seqs)]
+    rng = np.random.default_rng(8)
+    cobs = tmp_path / "cobs"
+    cobs.mkdir()
+    names, indexes = [], {}
+    with open(tmp_path / "sizes.txt", "w") as sz:
+        for b, (n_docs, S) in enumerate([(195, 40009), (664, 30011), (2300, 9001)]):
+            batch = f"genus_species{b}__01"
+            plant = [(qi, int(rng.integers(0, n_docs)), fr) for qi in range(0, len(lens), 3) for fr in (1.0, 0.9, 0.8, 0.7, 0.7, 0.69)]
+            index, fa2, _ = build_case(oracle, rng, n_docs, S, queries, plant=plant, density=0.2)
+            assert fa2 == fasta
+            (cobs / f"{batch}.cobs_classic.xz").write_bytes(lzma.compress(bytes(index), preset=0))
+            sz.write(f"cobs/{batch}.cobs_classic.xz  {len(index)}  1610678320\n")
+            names.append(batch)
+            indexes[batch] = index
+    (tmp_path / "batches.txt").write_text("\n".join(names) + "\n")
+    (tmp_path / "Q.fa").write_bytes(fasta)
+    r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"),
+                        "--cobs-dir", str(cobs), "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"),
+                        "--out-dir", str(tmp_path / "03_match"), "--nb-best-hits", "2", "--filter-out", str(tmp_path / "04_filter" / "Q.fa")],
+                       capture_output=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 2)

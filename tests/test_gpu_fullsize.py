@@ -127,6 +127,54 @@ def test_config3_full_size_sampled_parity_and_invariants(pm, oracle):
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], hits[hits["slot"] == pos])
 
 
+def test_gene_length_queries_on_config3_full_size(pm, oracle):
+    """SURVEY.md 8d's third query shape at BASELINE's index size: the 1 856 record lengths of data/ARGannot_r3.fa (10- and
+    13-plane counter classes) against the 64 full-size batches of config 3 (~213 GB resident, signature sizes up to
+    31.8 M rows); per batch the planted genes routed to it plus unplanted ones of both classes are checked exactly against
+    the oracle on the virtual matrix; exact algorithmic bytes; both scan modes give the same records"""
+    shapes = W.select("config3")
+    lens = W.argannot_lengths()
+    terms = [n - 30 for n in lens]
+    fasta, seqs = W.make_queries_lengths(lens, seed=43, prefix="gene")
+    arr = [np.frombuffer(s_, dtype=np.uint8) for s_ in seqs]
+    q = pm.Queries(fasta)
+    hashes = q.hash_terms(1, 1)
+    assert len(hashes) == sum(terms) == 1594532
+    off = np.concatenate([[0], np.cumsum(terms)])
+    for qi in (0, 7, 1855):
+        assert np.array_equal(hashes[off[qi]:off[qi + 1]], oracle.create_hashes(seqs[qi], 31, 1, 1))
+    plan, sure = W.plant_plan_ragged(hashes, terms, shapes, every=16, docs_per_query=6)
+    ixs = []
+    for pos, s in enumerate(shapes):
+        ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, seed=SEED)
+        if pos in plan:
+            ix.plant(*plan[pos])
+        ixs.append(ix)
+    try:
+        res = pm.search(ixs, q, 0.7)
+        hits = res.hits()
+        assert res.stats.algorithmic_bytes == 1594532 * 16285 and len(hits) >= sure > 300
+        assert {L["kernel"].split("P=")[1].split(",")[0] for L in res.launches()} == {"10", "13"}
+        long_ones = [i for i, t in enumerate(terms) if t >= 1024]
+        short_ones = [i for i, t in enumerate(terms) if t < 300]
+        checked = 0
+        for pos, s in enumerate(shapes):
+            planted = [qq for n, qq in enumerate(range(0, len(lens), 16)) if n % 64 == pos][:2]
+            sample = sorted(set(planted + [long_ones[pos % len(long_ones)], short_ones[(7 * pos) % len(short_ones)]]))
+            ov = _overlay(*plan[pos]) if pos in plan else {}
+            exp = _expected_hits(oracle, s, arr, sample, ov, 0.7)
+            sel = hits[(hits["slot"] == pos) & np.isin(hits["query"], sample)]
+            assert [(int(x["query"]), int(x["doc"]), int(x["score"])) for x in sel] == exp, s.batch
+            checked += len(exp)
+        assert checked >= 64 * 3
+        pm.set_option("threshold_bound", 0)
+        assert np.array_equal(pm.search(ixs, q, 0.7).hits(), hits)
+    finally:
+        pm.set_option("threshold_bound", 1)
+        for ix in ixs:
+            ix.free()
+
+
 def test_config1_bundled_reads_on_batches_small_shapes(pm, oracle, tmp_path):
     """BASELINE configs[0] shape: the reference's 40 bundled reads (data/reads_{1..4}) against the three
     batches of data/batches_small.txt at their real shapes (195/176/664 documents, 6.5M-16.5M rows),

@@ -92,9 +92,11 @@ class Admission:
             self.cv.notify_all()
 
 
-def open_index_stream(cobs_dir, batch, cache_dir=None):
-    """(file object, process or None): the plain index if it was decompressed
-    already (Snakefile:364-387; in <cache_dir> or next to the .xz), else an xzcat pipe (run_cobs_streaming.sh:27)"""
+def open_index_stream(cobs_dir, batch, cache_dir=None, xz_threads=1):
+    """(file object, decoder or None): the plain index if it was decompressed
+    already (Snakefile:364-387; in <cache_dir> or next to the .xz), else an xzcat pipe (run_cobs_streaming.sh:27) -- or,
+    with xz_threads > 1 and a file of several independent blocks, the in-process block-parallel decoder (xzpar.py);
+    the decoder has .wait() -> 0 on success"""
     for d in ([cache_dir] if cache_dir else []) + [cobs_dir]:
         plain = os.path.join(d, f"{batch}.cobs_classic")
         if os.path.exists(plain):
@@ -102,6 +104,12 @@ def open_index_stream(cobs_dir, batch, cache_dir=None):
     xz = os.path.join(cobs_dir, f"{batch}.cobs_classic.xz")
     if not os.path.exists(xz):
         raise FileNotFoundError(xz)
+    if xz_threads > 1:
+        from . import xzpar
+        pl = xzpar.plan(xz)
+        if pl is not None:
+            p = xzpar.ParallelXz(pl, min(xz_threads, len(pl.blocks)))
+            return p.stdout, p
     p = subprocess.Popen(["xzcat", "--no-sparse", "--ignore-check", xz], stdout=subprocess.PIPE)
     return p.stdout, p
 
@@ -137,7 +145,10 @@ class FileSource:
         self.pm, self.cobs_dir, self.sizes, self.cache_dir = pm, cobs_dir, sizes, cache_dir
         # host-RAM admission of the xz decoders (sizing.HostRam / sizing.stage_plan: the reference's max_ram_gb)
         self.host_ram, self.host_mb = host_ram, host_mb or {}
-        self.counts = {"xz_decoded": 0, "plain_files": 0, "cache_files_written": 0}
+        self.counts = {"xz_decoded": 0, "plain_files": 0, "cache_files_written": 0, "xz_decoded_block_parallel": 0}
+        # threads ONE multi-block .xz file is decoded with (xzpar.py): set by the stage when the rank has fewer compressed
+        # batches than CPUs (PHYLIGN_XZ_THREADS overrides; 1 = always xzcat)
+        self.xz_threads = 1
         self._mu = threading.Lock()
         # plain files are read by the library's own pread workers (6 per file, PM_LOAD_THREADS), which move 40+ GB/s out of
         # the page cache by themselves: the loader threads -- as many as xz decoders would need, sizing.stage_plan -- take
@@ -157,10 +168,11 @@ class FileSource:
     def load(self, batch):
         # a decoder is admitted to the host-RAM budget before it starts (a plain file needs only the pooled staging)
         mb = self.host_mb.get(batch, 0) if (self.host_ram is not None and self.is_compressed(batch)) else 0
+        mb *= max(1, self.xz_threads)                   # a block-parallel decode holds that many decoders (and their blocks)
         if mb:
             self.host_ram.acquire(mb)
         try:
-            fobj, proc = open_index_stream(self.cobs_dir, batch, self.cache_dir)
+            fobj, proc = open_index_stream(self.cobs_dir, batch, self.cache_dir, self.xz_threads)
             tee = os.path.join(self.cache_dir, f"{batch}.cobs_classic") if (self.cache_dir and proc is not None) else None
             ix = None
             try:
@@ -182,6 +194,7 @@ class FileSource:
                 self.host_ram.release(mb)
         with self._mu:
             self.counts["xz_decoded" if proc is not None else "plain_files"] += 1
+            self.counts["xz_decoded_block_parallel"] += int(proc is not None and not isinstance(proc, subprocess.Popen))
             self.counts["cache_files_written"] += int(bool(tee and getattr(ix, "cached", False)))
         return ix
 
@@ -745,6 +758,13 @@ def main(argv=None):
     if isinstance(source, FileSource):
         host_ram = source.host_ram = sizing.HostRam(budget_mb)
         source.host_mb = host_mb
+        # fewer compressed batches than CPUs (data/batches_small.txt: three): the CPUs left over decode the blocks of a
+        # multi-block file side by side (xzpar.py); with as many batches as CPUs one xzcat per loader already uses them all
+        n_xz = sum(1 for p_ in mine if source.is_compressed(batches[p_]))
+        my_cpus = max(1, effective_cpus() // local_world)
+        source.xz_threads = int(os.environ.get("PHYLIGN_XZ_THREADS", "0")) or (max(1, min(8, my_cpus // n_xz)) if n_xz else 1)
+        if source.xz_threads > 1:
+            args.loaders = max(1, min(args.loaders, max(1, my_cpus // source.xz_threads)))
     report, merge = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                               want_merge=bool(args.filter_out), write_match_files=not args.filter_only, loaders=args.loaders, budget_bytes=budget,
                               max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve)

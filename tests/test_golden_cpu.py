@@ -1449,3 +1449,44 @@ def test_oracle_equals_the_independent_restatement_on_compact_indexes(oracle, th
         c = oracle.compact_parse(index)
         assert (c.n_docs, c.page_size) == (D, page)
         assert oracle.query_file(index, fasta, threshold) == I.query_text_compact(records, names, mats, k, page, params, threshold), (seed, threshold)
+
+
+def test_block_parallel_xz_decoder_equals_xzcat(tmp_path):
+    """phylign_amd/xzpar.py: a multi-block .xz (`xz -T`, any integrity check) decoded block by block on several threads gives
+    the bytes xzcat gives; one-block files (plain `xz`, python's lzma, the reference's own data/*.xz), several streams and
+    non-xz input have no plan (the caller falls back to xzcat); a damaged block ends the stream early with status 1"""
+    import lzma
+    import subprocess
+    from phylign_amd import xzpar
+    rng = np.random.default_rng(12)
+    data = np.packbits(rng.random(24_000_000) < 0.25).tobytes() + bytes(rng.integers(0, 4, 1_500_001, dtype=np.uint8)) + b"tail"
+    src = tmp_path / "m.bin"
+    src.write_bytes(data)
+    for check in ("crc64", "crc32", "none", "sha256"):
+        out = tmp_path / f"m_{check}.xz"
+        with open(out, "wb") as f:
+            subprocess.run(["xz", "-T3", "-0", "--block-size=512KiB", f"--check={check}", "-c", str(src)], stdout=f, check=True)
+        pl = xzpar.plan(str(out))
+        assert pl is not None and len(pl.blocks) == (len(data) + (512 << 10) - 1) // (512 << 10) and pl.uncompressed_size == len(data)
+        for threads in (1, 5):
+            p = xzpar.ParallelXz(pl, threads)
+            assert p.stdout.read() == data and p.wait() == 0
+    one = tmp_path / "one.xz"
+    one.write_bytes(lzma.compress(data[:300000]))
+    assert xzpar.plan(str(one)) is None
+    two = tmp_path / "two.xz"
+    two.write_bytes((tmp_path / "m_crc64.xz").read_bytes() * 2)
+    assert xzpar.plan(str(two)) is None and xzpar.plan(str(src)) is None and xzpar.plan(str(tmp_path / "missing.xz")) is None
+    blob = bytearray((tmp_path / "m_crc64.xz").read_bytes())
+    blob[len(blob) // 3] ^= 0x55
+    bad = tmp_path / "bad.xz"
+    bad.write_bytes(bytes(blob))
+    pl = xzpar.plan(str(bad))
+    p = xzpar.ParallelXz(pl, 4)
+    got = p.stdout.read()
+    assert p.wait() == 1 and len(got) < len(data) and data.startswith(got) and p.error is not None
+    # a reader that goes away early does not hang the decoder
+    p = xzpar.ParallelXz(xzpar.plan(str(tmp_path / "m_crc64.xz")), 2)
+    p.stdout.read(1000)
+    p.stdout.close()
+    assert p.wait() == 1

@@ -650,8 +650,8 @@ def test_match_stage_decode_once_cache(pm, oracle, tmp_path):
         reports.append(json.loads([ln for ln in r.stderr.decode().splitlines() if ln.startswith("{")][-1]))
     # the block structure of the .xz files that were decoded (`xz --list`): python's lzma writes one block per file
     assert reports[0]["index_source"].pop("xz_blocks") == {"files": 5, "multi_block_files": 0, "blocks_max": 1, "blocks_total": 5}
-    assert reports[0]["index_source"] == {"xz_decoded": 5, "plain_files": 0, "cache_files_written": 5, "resident": 0}
-    assert reports[1]["index_source"] == {"xz_decoded": 0, "plain_files": 5, "cache_files_written": 0, "resident": 0}
+    assert reports[0]["index_source"] == {"xz_decoded": 5, "plain_files": 0, "cache_files_written": 5, "resident": 0, "xz_decoded_block_parallel": 0}
+    assert reports[1]["index_source"] == {"xz_decoded": 0, "plain_files": 5, "cache_files_written": 0, "resident": 0, "xz_decoded_block_parallel": 0}
     assert reports[2]["index_source"] == reports[1]["index_source"]
     plan = reports[0]["host_ram_plan"]
     assert plan["budget_mb"] == 4096 and plan["decoder_mb_max"] == 1537 + 64 and plan["loaders"] == 2
@@ -744,3 +744,44 @@ def test_match_stage_with_gene_length_queries(pm, oracle, tmp_path):
                        capture_output=True, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 2)
+
+
+def test_multi_block_xz_files_are_decoded_on_several_threads(pm, oracle, tmp_path):
+    """a rank with fewer compressed batches than CPUs (the reference's batches_small.txt has three) decodes the blocks of a
+    multi-block .xz file (`xz -T`) side by side in-process (phylign_amd/xzpar.py) instead of through one xzcat; outputs
+    and cache files are the same; a one-block file and PHYLIGN_XZ_THREADS=1 take the xzcat pipe"""
+    import json
+    names, indexes, fasta = _stage_fixture(oracle, tmp_path, n_batches=3)
+    for b in names[:2]:                                   # two batches as multi-block files, the third stays one block
+        xz = tmp_path / "cobs" / f"{b}.cobs_classic.xz"
+        plain = tmp_path / "cobs" / f"{b}.cobs_classic"
+        plain.write_bytes(bytes(indexes[b]))
+        xz.unlink()
+        subprocess.run(["xz", "-T2", "-0", "--block-size=64KiB", str(plain)], check=True)
+        assert not plain.exists()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "phylign_amd.match_stage", "--batches", str(tmp_path / "batches.txt"), "--cobs-dir", str(tmp_path / "cobs"),
+            "--sizes", str(tmp_path / "sizes.txt"), "--queries", str(tmp_path / "Q.fa"), "--nb-best-hits", "3"]
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_match"), "--filter-out", str(tmp_path / "04_filter" / "Q.fa"),
+                               "--cache-dir", str(tmp_path / "cache")], capture_output=True, env=dict(env, PHYLIGN_XZ_THREADS="4"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rep = json.loads([ln for ln in r.stderr.decode().splitlines() if ln.startswith("{")][-1])
+    assert rep["index_source"]["xz_decoded"] == 3 and rep["index_source"]["xz_decoded_block_parallel"] == 2
+    assert rep["index_source"]["xz_blocks"]["multi_block_files"] == 2 and rep["index_source"]["cache_files_written"] == 3
+    _check_stage_outputs(oracle, tmp_path, names, indexes, fasta, 3)
+    for b in names:
+        assert (tmp_path / "cache" / f"{b}.cobs_classic").read_bytes() == bytes(indexes[b])
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_one")], capture_output=True, env=dict(env, PHYLIGN_XZ_THREADS="1"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rep1 = json.loads([ln for ln in r.stderr.decode().splitlines() if ln.startswith("{")][-1])
+    assert rep1["index_source"]["xz_decoded_block_parallel"] == 0
+    for b in names:
+        assert (tmp_path / "03_one" / f"{b}____Q.gz").read_bytes() == (tmp_path / "03_match" / f"{b}____Q.gz").read_bytes()
+    # a damaged block: the stage fails, no cache entry for that batch
+    bad = tmp_path / "cobs" / f"{names[0]}.cobs_classic.xz"
+    blob = bytearray(bad.read_bytes())
+    blob[len(blob) // 2] ^= 0xFF
+    bad.write_bytes(bytes(blob))
+    r = subprocess.run(base + ["--out-dir", str(tmp_path / "03_bad"), "--cache-dir", str(tmp_path / "cache2")], capture_output=True,
+                       env=dict(env, PHYLIGN_XZ_THREADS="4"))
+    assert r.returncode != 0 and not (tmp_path / "cache2" / f"{names[0]}.cobs_classic").exists() and not list((tmp_path / "cache2").glob("*.tmp"))

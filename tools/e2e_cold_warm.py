@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--work", default="/tmp/phylign_cold_warm")
     ap.add_argument("--out", default=None)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--workload", default="full", help="full (a rank's shard of batches_full.txt) or small (the three batches of "
+                                                       "data/batches_small.txt at full size: fewer batches than CPUs, --world 1)")
+    ap.add_argument("--xz-block-mib", type=int, default=16)
     ap.add_argument("--modes", default="cold,cached,resident",
                     help="comma list of cold (xz -> HBM, fills the cache), cached (second run on the decode-once cache), plain "
                          "(decompressed .cobs_classic files in --cobs-dir: rule decompress_cobs / mem-disk, no .xz involved), resident.  "
@@ -68,7 +71,9 @@ def main():
 
     shutil.rmtree(args.work, ignore_errors=True)
     os.makedirs(os.path.join(args.work, "cobs"))
-    shapes = W.select("full")
+    shapes = W.select(args.workload)
+    if args.workload != "full":
+        args.world, args.rank = 1, 0
     mine = W.assign_batches(shapes, args.world)[args.rank]
     sub = W.scale_shapes([shapes[p] for p in mine], args.rows_divisor)
     pm.init(0)
@@ -114,7 +119,7 @@ def main():
     xz_bytes, t_xz = 0, 0.0
     if "cold" in modes:
         t0 = time.perf_counter()
-        subprocess.run(["xz", "-T0", args.xz_level, "--block-size=16MiB"] + files, check=True)
+        subprocess.run(["xz", "-T0", args.xz_level, f"--block-size={args.xz_block_mib}MiB"] + files, check=True)
         t_xz = time.perf_counter() - t0
         xz_bytes = sum(os.path.getsize(f + ".xz") for f in files)
         # the block structure the decoder would see (`xz --list`): blocks per file decide whether a file could be decoded
@@ -123,6 +128,13 @@ def main():
         blocks = [int(ln.split("\t")[2]) for ln in lst.splitlines() if ln.startswith("file\t")]
         rows["xz_list"] = {"files": len(blocks), "blocks_min": min(blocks), "blocks_max": max(blocks), "blocks_total": sum(blocks)}
         stage_row("cold", ["--cache-dir", cache])
+        if os.environ.get("COLD_ALSO_XZCAT"):
+            # the same cold run with one xzcat per file (PHYLIGN_XZ_THREADS=1), cache emptied first: what the
+            # block-parallel decoder buys when a rank has fewer compressed batches than CPUs
+            shutil.rmtree(cache, ignore_errors=True)
+            os.environ["PHYLIGN_XZ_THREADS"] = "1"
+            stage_row("cold_xzcat_only", ["--cache-dir", cache])
+            del os.environ["PHYLIGN_XZ_THREADS"]
     else:
         os.makedirs(cache, exist_ok=True)
         for f in files:                                      # what a cold run leaves in the cache: the decoded files
@@ -133,11 +145,12 @@ def main():
         stage_row("cached", ["--cache-dir", cache])
     first = [m for m in ("plain", "cold", "cached") if m in rows][0]
 
+
     def same_as_first(name):
         a, b = os.path.join(args.work, f"03_{first}"), os.path.join(args.work, f"03_{name}")
         ok_ = all(open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read() for f in os.listdir(a))
         return ok_ and open(os.path.join(args.work, f"04_{first}", "Q.fa"), "rb").read() == open(os.path.join(args.work, f"04_{name}", "Q.fa"), "rb").read()
-    same = all(same_as_first(m) for m in ("plain", "cold", "cached") if m in rows and m != first)
+    same = all(same_as_first(m) for m in ("plain", "cold", "cold_xzcat_only", "cached") if m in rows and m != first)
 
     # ---- resident: the matrices stay in HBM between query sets (server); in-process, load time outside the timer
     if "resident" in modes:
@@ -162,7 +175,7 @@ def main():
         rows["resident"] = {"e2e_s": round(res_rows[-1], 3), "match_only_s": rep["match_only_s"],
                             "plain_files_to_hbm_s_one_thread_of_loads": round(t_load, 3), "plain_files_to_hbm_GBps": plain_bytes / t_load / 1e9}
     line = {
-        "config": f"rank {args.rank} of {args.world} of batches_full.txt with rows / {args.rows_divisor}: {len(sub)} batches, "
+        "config": f"rank {args.rank} of {args.world} of batches_{args.workload}.txt with rows / {args.rows_divisor}: {len(sub)} batches, "
                   f"{plain_bytes / 1e9:.2f} GB of index files ({xz_bytes / 1e9:.2f} GB as .xz), {args.queries} x {args.qlen} bp queries, "
                   f"threshold 0.7, nb_best_hits 100, 03_match files + 04_filter FASTA; files under {args.work}",
         "index_GB": plain_bytes / 1e9,
@@ -171,7 +184,7 @@ def main():
         "note": "synthetic Bernoulli(1/4) signatures barely compress: the .xz decode is slower per output byte than on the real "
                 "661k indexes; a cold figure is conservative",
     }
-    for m in ("plain", "cold", "cached", "resident"):
+    for m in ("plain", "cold", "cold_xzcat_only", "cached", "resident"):
         if m in rows:
             line[m + "_s"] = rows[m]["e2e_s"]
     print(json.dumps(line), flush=True)

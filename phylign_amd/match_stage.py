@@ -92,6 +92,11 @@ class Admission:
             self.cv.notify_all()
 
 
+def xz_decode_threads(pl, xz_threads):
+    """threads the block-parallel decoder uses for a file with block table `pl` (None: not decodable that way -> 1)"""
+    return 1 if pl is None else max(1, min(int(xz_threads), len(pl.blocks)))
+
+
 def open_index_stream(cobs_dir, batch, cache_dir=None, xz_threads=1):
     """(file object, decoder or None): the plain index if it was decompressed
     already (Snakefile:364-387; in <cache_dir> or next to the .xz), else an xzcat pipe (run_cobs_streaming.sh:27) -- or,
@@ -108,7 +113,7 @@ def open_index_stream(cobs_dir, batch, cache_dir=None, xz_threads=1):
         from . import xzpar
         pl = xzpar.plan(xz)
         if pl is not None:
-            p = xzpar.ParallelXz(pl, min(xz_threads, len(pl.blocks)))
+            p = xzpar.ParallelXz(pl, xz_decode_threads(pl, xz_threads))
             return p.stdout, p
     p = subprocess.Popen(["xzcat", "--no-sparse", "--ignore-check", xz], stdout=subprocess.PIPE)
     return p.stdout, p
@@ -168,7 +173,9 @@ class FileSource:
     def load(self, batch):
         # a decoder is admitted to the host-RAM budget before it starts (a plain file needs only the pooled staging)
         mb = self.host_mb.get(batch, 0) if (self.host_ram is not None and self.is_compressed(batch)) else 0
-        mb *= max(1, self.xz_threads)                   # a block-parallel decode holds that many decoders (and their blocks)
+        if mb and self.xz_threads > 1:                  # a block-parallel decode holds that many decoders (and their blocks)
+            from . import xzpar
+            mb *= xz_decode_threads(xzpar.plan(os.path.join(self.cobs_dir, f"{batch}.cobs_classic.xz")), self.xz_threads)
         if mb:
             self.host_ram.acquire(mb)
         try:

@@ -111,15 +111,32 @@ class IndexCache:
             return e["ix"], key, True
         try:
             if path.endswith(".xz"):
-                p = subprocess.Popen(["xzcat", "--no-sparse", "--ignore-check", path], stdout=subprocess.PIPE)
+                # cold loads share the host's CPUs: with few of them in flight a file of several blocks (`xz -T`) is decoded
+                # block-parallel in-process (xzpar.py), else -- and for one-block files -- by one xzcat each
+                from . import xzpar
+                from .sysinfo import effective_cpus
+                with self.mu:
+                    self.cold_active = getattr(self, "cold_active", 0) + 1
+                    threads = int(os.environ.get("PHYLIGN_XZ_THREADS", "0")) or max(1, min(8, effective_cpus() // self.cold_active))
                 try:
-                    ix = self.pm.Index.load_fd(p.stdout.fileno(), size_hint=size_hint)
+                    pl = xzpar.plan(path) if threads > 1 else None
+                    if pl is not None:
+                        p = xzpar.ParallelXz(pl, min(threads, len(pl.blocks)))
+                    else:
+                        p = subprocess.Popen(["xzcat", "--no-sparse", "--ignore-check", path], stdout=subprocess.PIPE)
+                    ix = None
+                    try:
+                        ix = self.pm.Index.load_fd(p.stdout.fileno(), size_hint=size_hint)
+                    finally:
+                        p.stdout.close()
+                        rc = p.wait()
                 finally:
-                    p.stdout.close()
-                    rc = p.wait()
+                    with self.mu:
+                        self.cold_active -= 1
                 if rc != 0:
-                    ix.free()
-                    raise RuntimeError(f"xzcat failed on {path}")
+                    if ix is not None:
+                        ix.free()
+                    raise RuntimeError(f"xz decoding failed on {path}")
             else:
                 ix = self.pm.Index.load_file(path, size_hint=size_hint)
         except BaseException as err:

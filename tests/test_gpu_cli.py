@@ -438,6 +438,13 @@ def test_resident_index_server(pm, oracle, tmp_path):
         assert h1["ok"] and h1["cached"] and b1.decode() == P.filter_text(exp.decode(), 2)
         st, _ = request(sock, {"op": "stats"})
         assert st["loads"] == 1 and st["hits"] == 2 and st["resident"] == 1
+        # a cold load of a multi-block file (`xz -T`): decoded block-parallel in the server, same text
+        plain = tmp_path / "multi__01.cobs_classic"
+        plain.write_bytes(bytes(index))
+        subprocess.run(["xz", "-T2", "-0", "--block-size=1MiB", str(plain)], check=True)
+        h2, b2 = request(sock, {"op": "query", "index": str(plain) + ".xz", "index_size": len(index), "fasta_len": len(fasta),
+                                "threshold": 0.7}, fasta)
+        assert h2["ok"] and not h2["cached"] and b2 == exp
         bad, _ = request(sock, {"op": "query", "index": str(tmp_path / "missing.xz"), "fasta_len": 0})
         assert not bad["ok"]
         r = subprocess.run([script, "0.7", "1", str(tmp_path / "missing.xz"), "1", str(fa)], capture_output=True, env=cenv)

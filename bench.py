@@ -920,6 +920,17 @@ def main():
         "full_shard": full_shard,
         "full_collection": full_collection,
     }
+    if world > 1:
+        # what an N > 1 line leaves out, and why (the N = 1 line of the same run carries them)
+        why = {"argannot": "single-GPU leg: 1.6 M k-mers per file are not a multi-GPU workload; see the N = 1 line",
+               "l31": "single-GPU leg: bound by the read-back of hit records, not by the scan; see the N = 1 line",
+               "full_shard": "single-GPU stand-in for one rank of `full_collection`, which this line runs itself with 8+ ranks",
+               "clustered": "ships ~0.5 GB of records per step to rank 0; run with --clustered-multi to include it"}
+        for k_, v_ in why.items():
+            if out.get(k_) is None:
+                out[k_] = {"skipped": v_}
+        if out.get("full_collection") is None:
+            out["full_collection"] = {"skipped": f"runs with {min_world_full}+ ranks (all 305 batches need 8 x 135 GB of HBM)"}
     if args.emulate_world:
         out["emulated_shard"] = f"rank {part_id} of {nparts}"
     if rank == 0 and not args.emulate_world and run_head["hits"] is not None:

@@ -216,7 +216,9 @@ void pm_queries_free(pm_queries_t* q);
 /* Frees the HBM copies of the query set (sequences, descriptors, hash buffers: about 8 bytes per k-mer and hash function)
  * and keeps the host side -- names and sequences, which results, texts and the 04_filter merge refer to.  The next search
  * uploads them again.  For a query file searched chunk after chunk (pm_fasta_record_cuts): a chunk that is not searched
- * for a while need not stay resident.  Waits only for searches that were queued with THIS set. */
+ * for a while need not stay resident.  Waits only for searches that were queued with THIS set.  The buffers go to a small
+ * pool inside the library that the next query set draws from (a hipFree would wait for every search queued behind);
+ * pm_set_option("release_query_pool", 1) really frees them. */
 int  pm_queries_release_device(pm_queries_t* q);
 /* *resident: HBM bytes the set holds now; *when_searched: what it holds while searched against indexes of num_hashes
  * hash functions (either may be NULL) */

@@ -219,6 +219,9 @@ def _check_multi_rank_line(line, n):
     assert "rccl_ranks" in line["participants"]          # null over gloo (these tests), N over RCCL
     ur = line["unique_rows"]
     assert ur and 0 < ur["unique_rows_x_row_bytes"] <= ur["algorithmic_bytes_per_step"] and ur["unique_rows"] <= ur["rows_resident"]
+    for leg in ("argannot", "l31", "full_shard"):                  # single-GPU legs: left out WITH the reason, never a bare null
+        assert "skipped" in line[leg], leg
+    assert line["full_collection"] is not None and line["clustered"] is not None
 
 
 def test_bench_two_ranks_equal_one_rank(pm, tmp_path):

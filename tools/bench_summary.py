@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""prints the figures of a bench line that the round's notes quote: python tools/r05_summary.py <bench.json>"""
+"""prints the figures of a bench line that the round's notes quote: python tools/bench_summary.py <bench.json>"""
 import json
 import sys
 

@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--workload", default="full", help="full (a rank's shard of batches_full.txt) or small (the three batches of "
                                                        "data/batches_small.txt at full size: fewer batches than CPUs, --world 1)")
     ap.add_argument("--xz-block-mib", type=int, default=16)
+    ap.add_argument("--cold-without-cache", action="store_true",
+                    help="the cold run decodes straight into HBM and keeps nothing (the reference's default mem-stream mode): the "
+                         "full-size shard as .xz (112 GB) plus a 128 GB cache would not fit a memory-backed --work")
     ap.add_argument("--modes", default="cold,cached,resident",
                     help="comma list of cold (xz -> HBM, fills the cache), cached (second run on the decode-once cache), plain "
                          "(decompressed .cobs_classic files in --cobs-dir: rule decompress_cobs / mem-disk, no .xz involved), resident.  "
@@ -127,7 +130,7 @@ def main():
         lst = subprocess.run(["xz", "--robot", "--list"] + [f + ".xz" for f in files], capture_output=True, text=True).stdout
         blocks = [int(ln.split("\t")[2]) for ln in lst.splitlines() if ln.startswith("file\t")]
         rows["xz_list"] = {"files": len(blocks), "blocks_min": min(blocks), "blocks_max": max(blocks), "blocks_total": sum(blocks)}
-        stage_row("cold", ["--cache-dir", cache])
+        stage_row("cold", [] if args.cold_without_cache else ["--cache-dir", cache])
         if os.environ.get("COLD_ALSO_XZCAT"):
             # the same cold run with one xzcat per file (PHYLIGN_XZ_THREADS=1), cache emptied first: what the
             # block-parallel decoder buys when a rank has fewer compressed batches than CPUs

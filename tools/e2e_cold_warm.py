@@ -9,6 +9,11 @@ product's stage (phylign_amd.match_stage, as a subprocess, exactly the command a
   resident  the matrices are in HBM already (what phylign_amd.server keeps between query sets): in-process run_stage
 
     python3 tools/e2e_cold_warm.py --rows-divisor 8 --queries 100000 --work /tmp/cw --out gpurun_out/r04/cold_warm.json
+    python3 tools/e2e_cold_warm.py --rows-divisor 1 --modes plain,cached,resident --work /dev/shm/pf ...     (full size, no .xz)
+    python3 tools/e2e_cold_warm.py --rows-divisor 1 --modes cold --cold-without-cache --work /dev/shm/pcf ... (full size, xz -> HBM)
+    COLD_ALSO_XZCAT=1 python3 tools/e2e_cold_warm.py --workload small --rows-divisor 1 --xz-block-mib 24 ... (3 batches: block-parallel vs xzcat)
+
+  plain     the decompressed files in --cobs-dir (rule decompress_cobs), no .xz involved
 
 Synthetic Bernoulli(1/4) signatures are nearly incompressible (0.81 bits of entropy per bit), so these .xz files are
 about as large as the plain ones and decode SLOWER per output byte than the real 661k indexes (which shrink ~10x): the

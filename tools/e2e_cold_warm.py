@@ -109,6 +109,7 @@ def main():
             sz.write(f"cobs/{s.batch}.cobs_classic.xz  {n}  1610678320\n")
             bl.write(s.batch + "\n")
     t_save = time.perf_counter() - t0
+    print(f"[cold_warm] {len(sub)} index files ({plain_bytes / 1e9:.2f} GB) saved in {t_save:.1f} s", file=sys.stderr, flush=True)
     files = [os.path.join(args.work, "cobs", f"{s.batch}.cobs_classic") for s in sub]
     q.free()
     pm.shutdown()                                            # the stage runs are processes of their own
@@ -130,6 +131,7 @@ def main():
         subprocess.run(["xz", "-T0", args.xz_level, f"--block-size={args.xz_block_mib}MiB"] + files, check=True)
         t_xz = time.perf_counter() - t0
         xz_bytes = sum(os.path.getsize(f + ".xz") for f in files)
+        print(f"[cold_warm] xz {args.xz_level} of {plain_bytes / 1e9:.2f} GB took {t_xz:.1f} s -> {xz_bytes / 1e9:.2f} GB", file=sys.stderr, flush=True)
         # the block structure the decoder would see (`xz --list`): blocks per file decide whether a file could be decoded
         # by several threads at all
         lst = subprocess.run(["xz", "--robot", "--list"] + [f + ".xz" for f in files], capture_output=True, text=True).stdout

@@ -128,7 +128,9 @@ def main():
     xz_bytes, t_xz = 0, 0.0
     if "cold" in modes:
         t0 = time.perf_counter()
-        subprocess.run(["xz", "-T0", args.xz_level, f"--block-size={args.xz_block_mib}MiB"] + files, check=True)
+        # (-T = the CPUs the job may use, not -T0: with a cgroup quota of 16 on a 256-thread host, 256 xz threads thrash)
+        from phylign_amd.sysinfo import effective_cpus
+        subprocess.run(["xz", f"-T{effective_cpus()}", args.xz_level, f"--block-size={args.xz_block_mib}MiB"] + files, check=True)
         t_xz = time.perf_counter() - t0
         xz_bytes = sum(os.path.getsize(f + ".xz") for f in files)
         print(f"[cold_warm] xz {args.xz_level} of {plain_bytes / 1e9:.2f} GB took {t_xz:.1f} s -> {xz_bytes / 1e9:.2f} GB", file=sys.stderr, flush=True)

@@ -195,7 +195,7 @@ class FileSource:
                     # removed (another process decoding the same batch writes its own temporary and may have finished well)
                     if tee and ix is not None and getattr(ix, "cached", False) and os.path.exists(tee):
                         os.unlink(tee)
-                    raise RuntimeError(f"xzcat failed on batch {batch}")
+                    raise RuntimeError(f"xz decoding failed on batch {batch}")
         finally:
             if mb:
                 self.host_ram.release(mb)

@@ -40,9 +40,15 @@ def stage_cmd(work, out_dir, filt, extra):
             "--queries", os.path.join(work, "Q.fa"), "--out-dir", out_dir, "--filter-out", filt] + extra
 
 
+STAGE_TIMEOUT_S = float(os.environ.get("STAGE_TIMEOUT_S", "0")) or None
+
+
 def run_stage_cmd(cmd):
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    try:
+        r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, PYTHONPATH=ROOT), timeout=STAGE_TIMEOUT_S)
+    except subprocess.TimeoutExpired as e:
+        sys.exit(f"stage did not finish within {STAGE_TIMEOUT_S} s; stderr tail:\n" + (e.stderr or b"").decode(errors="replace")[-3000:])
     wall = time.perf_counter() - t0
     if r.returncode != 0:
         sys.exit(r.stderr.decode()[-3000:])

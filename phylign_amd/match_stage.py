@@ -268,7 +268,7 @@ def split_prepared_fasta(fasta, max_records, piece_bytes=0):
 
 def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7, nb_best_hits=100,
               want_merge=False, loaders=4, budget_bytes=None, max_group=0, keep_texts=None, kmer_size=31,
-              query_reserve_bytes=0, write_match_files=True):
+              query_reserve_bytes=0, write_match_files=True, load_order=None):
     """The per-rank pipeline described in the module docstring over the batches `mine` (positions into
     `batches`).  `queries` is one pm.Queries or a LIST of them (or of Futures of them: a file that is still being parsed):
     the chunks, in file order, of a query file with more reads than fit HBM at once, or of one cut up so that parsing and
@@ -445,7 +445,12 @@ def run_stage(pm, batches, mine, source, queries, qfile, out_dir, threshold=0.7,
             # 0.17 / 0.17 / 0.15 s with 2 / 3 / 4 / 8 groups, match-only 0.131 -> 0.137 s: profiles/r03/NOTES.md section 6)
             max_group = (len(mine) + 3) // 4
     with ThreadPoolExecutor(max_workers=max(1, loaders)) as pool:
-        futures = [] if resident else [pool.submit(load, ticket, pos) for ticket, pos in enumerate(mine)]
+        # load_order: the order in which the loaders take the batches (a permutation of `mine`; default: as listed).  The
+        # stage passes "largest compressed index first": the decoders are the slow part of a cold run, and with the big
+        # files started first the last ones to finish are small (longest-processing-time-first over the loader threads)
+        order = list(mine) if load_order is None else list(load_order)
+        assert sorted(order) == sorted(mine)
+        futures = [] if resident else [pool.submit(load, ticket, pos) for ticket, pos in enumerate(order)]
         try:
             left, pending, backlog = len(mine), None, []
             while left or backlog or pending:
@@ -761,7 +766,7 @@ def main(argv=None):
     max_ram_gb = (args.max_ram_gb if args.max_ram_gb > 0 else 0.8 * available_ram_gb()) / local_world
     args.loaders, budget_mb, host_mb = sizing.stage_plan([batches[p_] for p_ in mine], args.sizes,
                                                         max(1, effective_cpus() // local_world), max_ram_gb, args.loaders)
-    host_ram = None
+    host_ram, load_order = None, None
     if isinstance(source, FileSource):
         host_ram = source.host_ram = sizing.HostRam(budget_mb)
         source.host_mb = host_mb
@@ -772,9 +777,11 @@ def main(argv=None):
         source.xz_threads = int(os.environ.get("PHYLIGN_XZ_THREADS", "0")) or (max(1, min(8, my_cpus // n_xz)) if n_xz else 1)
         if source.xz_threads > 1:
             args.loaders = max(1, min(args.loaders, max(1, my_cpus // source.xz_threads)))
+        # compressed batches first, the largest first (the sizes table knows them); plain files behind them in list order
+        load_order = sorted(mine, key=lambda p_: (0, -int(sizes.get(batches[p_], 0)), p_) if source.is_compressed(batches[p_]) else (1, 0, p_))
     report, merge = run_stage(pm, batches, mine, source, chunk_list, qfile, args.out_dir, args.threshold, args.nb_best_hits,
                               want_merge=bool(args.filter_out), write_match_files=not args.filter_only, loaders=args.loaders, budget_bytes=budget,
-                              max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve)
+                              max_group=args.max_group, kmer_size=args.kmer_size, query_reserve_bytes=reserve, load_order=load_order)
     parser.shutdown()
     del fasta
     if isinstance(source, FileSource) and report["index_source"].get("xz_decoded"):

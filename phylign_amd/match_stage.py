@@ -755,7 +755,6 @@ def main(argv=None):
     # a query set holds about 9 bytes of HBM per base while it is searched (sequence + 8 bytes of hash per k-mer); two chunks
     # are resident at a time
     reserve = 9 * sum(sorted((len(p_) for p_ in pieces), reverse=True)[:2])
-    query_bytes = sum(len(p_) for p_ in pieces)
     del pieces
     # loaders and their host RAM by the reference's sizing rules (Snakefile:60-121 -> sizing.py): the decoder size of every
     # batch of this rank from the sizes table, the budget from --max-ram-gb
@@ -766,10 +765,7 @@ def main(argv=None):
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world))
     max_ram_gb = (args.max_ram_gb if args.max_ram_gb > 0 else 0.8 * available_ram_gb()) / local_world
     args.loaders, budget_mb, host_mb = sizing.stage_plan([batches[p_] for p_ in mine], args.sizes,
-                                                        max(1, effective_cpus() // local_world), max_ram_gb, args.loaders,
-                                                        # the host half (text, deflate, merge) of a small query file is idle most of
-                                                        # the time: its CPUs decode instead (a cold run is decoder-bound)
-                                                        reserve_cpus=4 if query_bytes > (64 << 20) else 2)
+                                                        max(1, effective_cpus() // local_world), max_ram_gb, args.loaders)
     host_ram, load_order = None, None
     if isinstance(source, FileSource):
         host_ram = source.host_ram = sizing.HostRam(budget_mb)

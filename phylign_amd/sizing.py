@@ -64,16 +64,15 @@ def loader_host_mb(batch, sizes_path):
         return 1536 + STAGING_MB                       # not in the table: the 661k files' decoder size (1.5 GiB)
 
 
-def stage_plan(batches, sizes_path, cpus, max_ram_gb, loaders=0, reserve_cpus=4):
+def stage_plan(batches, sizes_path, cpus, max_ram_gb, loaders=0):
     """(number of loader threads, host-RAM budget in MB, {batch: MB one loader of it needs}).  The budget is the
     reference's `max_ram_gb` (config.yaml:53-58: the RAM its jobs may hold together; Snakemake admits a job while the sum
-    of the running jobs' max_ram_mb fits).  loaders = 0: as many as the CPUs allow (all but `reserve_cpus` -- what the host
-    half of the stage, text + deflate + merge, keeps busy: 4 for a large query file, 2 for a small one --, at least 4, at
-    most 16: one xz stream decodes 0.03-0.2 GB/s on one core) and as fit the budget at the largest decoder size."""
+    of the running jobs' max_ram_mb fits).  loaders = 0: as many as the CPUs allow (all but 4, at least 4, at most 16: one
+    xz stream decodes 0.1-0.2 GB/s on one core) and as fit the budget at the largest decoder size."""
     need = {b: loader_host_mb(b, sizes_path) for b in batches}
     budget_mb = int(max_ram_gb * 1024)
     if loaders <= 0:
-        loaders = max(4, min(16, cpus - reserve_cpus))
+        loaders = max(4, min(16, cpus - 4))
         if need and budget_mb > 0:
             loaders = max(1, min(loaders, budget_mb // max(need.values())))
     return loaders, budget_mb, need

@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--workload", default="full", help="full (a rank's shard of batches_full.txt) or small (the three batches of "
                                                        "data/batches_small.txt at full size: fewer batches than CPUs, --world 1)")
     ap.add_argument("--xz-block-mib", type=int, default=16)
+    ap.add_argument("--compressible", action="store_true",
+                    help="files with compressible content (bench_aids.index_correlate: runs of equal bits along a row) instead of "
+                         "Bernoulli(1/4) bits: the .xz then shrinks and decodes like a real index does; no planted hits (outputs are "
+                         "still compared between the modes)")
     ap.add_argument("--cold-without-cache", action="store_true",
                     help="the cold run decodes straight into HBM and keeps nothing (the reference's default mem-stream mode): the "
                          "full-size shard as .xz (112 GB) plus a 128 GB cache would not fit a memory-backed --work")
@@ -105,7 +109,9 @@ def main():
     with open(os.path.join(args.work, "sizes.txt"), "w") as sz, open(os.path.join(args.work, "batches.txt"), "w") as bl:
         for i, s in enumerate(sub):
             ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, 661)
-            if i in plan:
+            if args.compressible:
+                bench_aids.index_correlate(ix, seed=7 + i)
+            elif i in plan:
                 ix.plant(*plan[i])
             path = os.path.join(args.work, "cobs", f"{s.batch}.cobs_classic")
             bench_aids.index_save(ix, path)
@@ -199,8 +205,10 @@ def main():
         "index_GB": plain_bytes / 1e9,
         "outputs_identical": bool(same), "planted_pairs_at_or_above_threshold": sure,
         "host_cpus": len(os.sched_getaffinity(0)), "runs": rows,
-        "note": "synthetic Bernoulli(1/4) signatures barely compress: the .xz decode is slower per output byte than on the real "
-                "661k indexes; a cold figure is conservative",
+        "note": ("compressible content (--compressible): runs of equal bits along a row; xz ratio and decode speed in the range of real indexes"
+                 if args.compressible else
+                 "synthetic Bernoulli(1/4) signatures barely compress: the .xz decode is slower per output byte than on the real "
+                 "661k indexes; a cold figure is conservative"),
     }
     for m in ("plain", "cold", "cold_xzcat_only", "cached", "resident"):
         if m in rows:

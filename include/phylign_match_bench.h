@@ -47,9 +47,9 @@ void pm_bench_hashes_free(pm_bench_hashes_t* h);
 int pm_bench_index_plant_cluster(pm_index_t* idx, const pm_bench_hashes_t* h, uint32_t q_first, uint32_t q_step, uint64_t seed);
 
 /* For cold-path timings only: overwrites the resident matrix with COMPRESSIBLE content (along a row, a document repeats its
- * neighbour's bit except with probability 1/16), so that the .xz of a saved index shrinks the way the real 661k indexes do
+ * neighbour's bit except with probability 2^-flip_log2; 7 gives an xz ratio near 0.1), so that the .xz of a saved index shrinks the way the real 661k indexes do
  * (Bernoulli(1/4) bits barely compress).  Nothing meaningful can be searched on such a matrix. */
-int pm_bench_index_correlate(pm_index_t* idx, uint64_t seed);
+int pm_bench_index_correlate(pm_index_t* idx, uint64_t seed, uint32_t flip_log2);
 
 /* SURVEY.md 8d, many-queries regime: the number of DISTINCT signature rows the query set's k-mers map to in this index
  * (unique_rows x row_bytes is what a scan with perfect row reuse would have to read; reported beside the algorithmic bytes) */

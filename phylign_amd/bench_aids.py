@@ -22,7 +22,7 @@ SYMBOLS = [
     ("pm_bench_index_plant_cluster", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint64]),
     ("pm_bench_index_save", C.c_int, [_P, C.c_char_p]),
     ("pm_bench_unique_rows", C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
-    ("pm_bench_index_correlate", C.c_int, [_P, C.c_uint64]),
+    ("pm_bench_index_correlate", C.c_int, [_P, C.c_uint64, C.c_uint32]),
     ("pm_bench_probe_gather", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 ]
 _aids = None
@@ -115,9 +115,9 @@ def probe_gather(index, n_groups, lookups_per_group, mode=None, flavor=None, unr
     return ms.value, nb.value
 
 
-def index_correlate(index, seed=7):
+def index_correlate(index, seed=7, flip_log2=7):
     """cold-path timings only: overwrites the resident matrix with compressible content (see the header)"""
-    _chk(load().pm_bench_index_correlate(index._h, seed))
+    _chk(load().pm_bench_index_correlate(index._h, seed, flip_log2))
 
 
 def index_save(index, path):

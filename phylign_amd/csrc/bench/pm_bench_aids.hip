@@ -458,16 +458,21 @@ extern "C" int pm_bench_probe_gather(const pm_index_t* ix, uint64_t n_groups, ui
 
 // Compressible content for the COLD-PATH timing only.  Bernoulli(1/4) bits barely compress (xz keeps 87 % of them), while the
 // real 661k indexes shrink about tenfold because neighbouring documents of a phylogenetic batch share most k-mers.  This
-// overwrites a resident matrix with rows in which document d repeats document d - 1's bit except with probability 1/16
+// overwrites a resident matrix with rows in which document d repeats document d - 1's bit except with probability 2^-flip_log2
 // (runs of equal bits along a row); the search results on such a matrix mean nothing and nothing is searched on it.
-__global__ __launch_bounds__(256) void k_correlate(uint8_t* matrix, uint64_t stride, uint64_t S, uint32_t n_docs, uint64_t seed) {
+__global__ __launch_bounds__(256) void k_correlate(uint8_t* matrix, uint64_t stride, uint64_t S, uint32_t n_docs, uint64_t seed, uint32_t flip_log2) {
     const uint32_t n_dw = (n_docs + 31u) >> 5;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < S; r += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t* row = reinterpret_cast<uint32_t*>(matrix + r * stride);
         uint32_t carry = (uint32_t)(splitmix64(seed ^ (r * 0x9E3779B97F4A7C15ULL)) & 1u);
         for (uint32_t w = 0; w < n_dw; ++w) {
-            const uint64_t a = splitmix64(seed + r * 0xD1B54A32D192ED03ULL + w), b = splitmix64(a ^ 0xA5A5A5A5A5A5A5A5ULL);
-            uint32_t x = (uint32_t)a & (uint32_t)(a >> 32) & (uint32_t)b & (uint32_t)(b >> 32);     // flips, density 1/16
+            uint64_t a = splitmix64(seed + r * 0xD1B54A32D192ED03ULL + w);
+            uint32_t x = 0xFFFFFFFFu;                                                             // flips, density 2^-flip_log2
+            for (uint32_t i = 0; i < flip_log2; i += 2) {
+                x &= (uint32_t)a;
+                if (i + 1 < flip_log2) x &= (uint32_t)(a >> 32);
+                a = splitmix64(a ^ 0xA5A5A5A5A5A5A5A5ULL);
+            }
             x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;                     // prefix xor: runs
             if (carry) x = ~x;
             carry = x >> 31;
@@ -477,12 +482,12 @@ __global__ __launch_bounds__(256) void k_correlate(uint8_t* matrix, uint64_t str
         }
     }
 }
-extern "C" int pm_bench_index_correlate(pm_index_t* ix, uint64_t seed) {
-    if (!ix) return bfail(PM_EINVAL, "bad argument");
+extern "C" int pm_bench_index_correlate(pm_index_t* ix, uint64_t seed, uint32_t flip_log2) {
+    if (!ix || flip_log2 == 0 || flip_log2 > 16) return bfail(PM_EINVAL, "bad argument");
     uint8_t* m = nullptr; uint64_t stride = 0; pm_index_info_t info;
     { int rc = bind_to(ix, &m, &stride, &info); if (rc) return rc; }
     hipLaunchKernelGGL(k_correlate, dim3((uint32_t)std::min<uint64_t>((info.signature_size + 255) / 256, 262144)), dim3(256), 0, nullptr,
-                       m, stride, info.signature_size, info.n_docs, seed);
+                       m, stride, info.signature_size, info.n_docs, seed, flip_log2);
     BHIP(hipGetLastError());
     BHIP(hipStreamSynchronize(nullptr));
     return PM_OK;

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--workload", default="full", help="full (a rank's shard of batches_full.txt) or small (the three batches of "
                                                        "data/batches_small.txt at full size: fewer batches than CPUs, --world 1)")
     ap.add_argument("--xz-block-mib", type=int, default=16)
+    ap.add_argument("--flip-log2", type=int, default=7, help="--compressible: a bit differs from its neighbour's with probability 2^-n")
     ap.add_argument("--compressible", action="store_true",
                     help="files with compressible content (bench_aids.index_correlate: runs of equal bits along a row) instead of "
                          "Bernoulli(1/4) bits: the .xz then shrinks and decodes like a real index does; no planted hits (outputs are "
@@ -110,7 +111,7 @@ def main():
         for i, s in enumerate(sub):
             ix = pm.Index.synth(s.batch_id, s.n_docs, s.signature_size, 1, 31, 661)
             if args.compressible:
-                bench_aids.index_correlate(ix, seed=7 + i)
+                bench_aids.index_correlate(ix, seed=7 + i, flip_log2=args.flip_log2)
             elif i in plan:
                 ix.plant(*plan[i])
             path = os.path.join(args.work, "cobs", f"{s.batch}.cobs_classic")

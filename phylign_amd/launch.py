@@ -23,6 +23,16 @@ def free_port():
         return s.getsockname()[1]
 
 
+def reserve_port():
+    """(socket, port): a free port that STAYS bound -- not listening, SO_REUSEADDR -- for as long as the socket is open.  The
+    rendezvous store of rank 0 (which binds with SO_REUSEADDR too) can still listen on it, while a process that merely asks
+    for a free port, or binds without the option, cannot take it between this call and rank 0's bind."""
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    s.bind(("127.0.0.1", 0))
+    return s, s.getsockname()[1]
+
+
 def wants_self_launch(n_gpus, environ=None):
     """True when the command line asks for several ranks and no launcher provided them"""
     env = os.environ if environ is None else environ
@@ -56,10 +66,9 @@ def spawn_ranks(cmd, world, poll_s=0.2, grace_s=10.0, extra_env=None):
     """Runs `cmd` (argv list) once per rank and waits.  Returns the exit status of the job: 0 when every rank
     returned 0, else the first failing rank's status (a rank killed by signal n counts as 128 + n).  A failing rank, or
     SIGINT / SIGTERM to the launcher, ends the others the same way: SIGTERM to their process groups, `grace_s` seconds,
-    then SIGKILL -- a rank stuck in a collective does not keep its GPU.
-    (MASTER_PORT is a port that was free a moment ago: between free_port() and rank 0's bind another process could take
-    it; the launchers of the driver pass their own --master-port, this path is the convenience form.)"""
-    port = free_port()
+    then SIGKILL -- a rank stuck in a collective does not keep its GPU.  MASTER_PORT is held bound by the launcher
+    (reserve_port) until the ranks are gone, so nobody else is handed it between its choice and rank 0's bind."""
+    holder, port = reserve_port()
     launcher = {"PHYLIGN_LAUNCHER_PID": str(os.getpid())}
     # start_new_session: every rank leads its own process group (ended as a group); no code runs between fork and exec
     procs = [subprocess.Popen(cmd, env=dict(rank_env(r, world, port), **launcher, **(extra_env or {})), start_new_session=True)
@@ -111,6 +120,7 @@ def spawn_ranks(cmd, world, poll_s=0.2, grace_s=10.0, extra_env=None):
                 pass
         for s_, h in old.items():
             signal.signal(s_, h)
+        holder.close()
     return status
 
 

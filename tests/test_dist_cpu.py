@@ -394,3 +394,24 @@ def test_match_stage_refuses_abbreviated_options():
     r = subprocess.run([sys.executable, "-m", "phylign_amd.match_stage", "--synthetic", "small", "--queries", os.devnull, "--out-dir", os.devnull,
                         "--thresh", "0.5"], capture_output=True, timeout=120, env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 2 and b"unrecognized arguments: --thresh" in r.stderr
+
+
+def test_self_launched_ranks_rendezvous_on_the_port_the_launcher_holds(tmp_path):
+    """the launcher keeps MASTER_PORT bound (not listening) while the ranks start, so that nobody else is handed the port;
+    rank 0's store still binds and listens on it: two ranks form a gloo group through env:// and reduce"""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, datetime\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=60))\n"
+        "t = torch.tensor([dist.get_rank() + 1]); dist.all_reduce(t)\n"
+        "open(os.path.join(sys.argv[1], 'sum%d' % dist.get_rank()), 'w').write(str(int(t)))\n"
+        "dist.destroy_process_group()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom phylign_amd import launch\n"
+            "sys.exit(launch.self_launch_script(%r, sys.argv[1:], 2))\n" % (root, str(script)))
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, timeout=180)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert (tmp_path / "sum0").read_text() == "3" and (tmp_path / "sum1").read_text() == "3"

@@ -415,3 +415,48 @@ def test_self_launched_ranks_rendezvous_on_the_port_the_launcher_holds(tmp_path)
     r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, timeout=180)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert (tmp_path / "sum0").read_text() == "3" and (tmp_path / "sum1").read_text() == "3"
+
+
+def test_gene_length_workload_helpers():
+    """the query shape of the reference's bundled gene file: the committed lengths fixture, the ragged query
+    maker and the ragged planting plan (fractions that straddle the threshold, per-query k-mer counts)"""
+    from phylign_amd import workload as W
+    lens = W.argannot_lengths()
+    assert len(lens) == 1856 and (min(lens), max(lens)) == (237, 3153) and sum(n - 30 for n in lens) == 1594532
+    assert sum(1 for n in lens if n - 30 < 1024) == 1514                      # 10-plane class; the other 342 are 13-plane
+    fasta, seqs = W.make_queries_lengths(lens[:5], seed=3, prefix="g")
+    assert [len(s_) for s_ in seqs] == lens[:5] and fasta.count(b">g") == 5 and set(fasta) <= set(b">g0123456789ACGT\n")
+    assert W.make_queries_lengths(lens[:5], seed=3, prefix="g")[0] == fasta   # seeded
+    terms = [n - 30 for n in lens[:40]]
+    hashes = np.arange(sum(terms), dtype=np.uint64) * np.uint64(2654435761)
+    shapes = W.select("small")
+    plan, sure = W.plant_plan_ragged(hashes, terms, shapes, every=8, docs_per_query=6, threshold=0.7)
+    assert set(plan) <= set(range(len(shapes))) and sure == 5 * 4                # 5 planted queries x 4 of 6 fractions reach 0.7
+    off = np.concatenate([[0], np.cumsum(terms)])
+    for pos, (rows, docs) in plan.items():
+        assert len(rows) == len(docs) and rows.max() < shapes[pos].signature_size and docs.max() < shapes[pos].n_docs
+    # the rows of a planted (query, document) pair are the query's first ceil(f x k-mers) rows, for the fractions in order
+    q0_rows = (hashes[off[0]:off[1]] % np.uint64(shapes[0].signature_size))
+    rows0, docs0 = plan[0]
+    first_doc = docs0[0]
+    n_first = int(np.count_nonzero(docs0[:terms[0]] == first_doc))
+    assert n_first == terms[0] and np.array_equal(rows0[:n_first], q0_rows)      # fraction 1.0 comes first
+
+
+def test_xz_probe_and_thread_choice(tmp_path):
+    """match_stage.xz_block_structure (`xz --robot --list`) and the thread count the block-parallel decoder gets"""
+    import lzma
+    import subprocess
+    from phylign_amd import match_stage as MS
+    from phylign_amd import xzpar
+    one = tmp_path / "a.xz"
+    one.write_bytes(lzma.compress(os.urandom(50000)))
+    multi = tmp_path / "b"
+    multi.write_bytes(os.urandom(3 << 20))
+    subprocess.run(["xz", "-T2", "-0", "--block-size=1MiB", str(multi)], check=True)
+    st = MS.xz_block_structure([str(one), str(multi) + ".xz", str(tmp_path / "missing.xz")])
+    assert st == {"files": 2, "multi_block_files": 1, "blocks_max": 3, "blocks_total": 4}
+    assert MS.xz_block_structure([str(tmp_path / "missing.xz")]) is None
+    assert MS.xz_decode_threads(None, 8) == 1
+    pl = xzpar.plan(str(multi) + ".xz")
+    assert MS.xz_decode_threads(pl, 8) == 3 and MS.xz_decode_threads(pl, 2) == 2 and MS.xz_decode_threads(xzpar.plan(str(one)), 8) == 1

@@ -67,6 +67,100 @@ def kernel_blob_hash():
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
+# ---- the line the driver parses -------------------------------------------------------------------------------------
+# The LAST stdout line of bench.py is a small strict-JSON object (headline + roofline + cpu_baseline + who took part); the
+# auxiliary legs (threshold_bound, unique_rows, argannot, clustered, l31, full_shard, full_collection, per-launch and
+# per-rank detail) go to a side file (--legs-out) that holds the whole record.  Round 5's single 28.6 KB line came back
+# from the driver unparsed (BENCH_r05.json: "parsed": null); the line is therefore capped and the cap is tested.
+LINE_MAX_BYTES = 6144
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "roofline_narrow", "cpu_baseline", "gpu_over_cpu",
+             "participants", "pm_kernels_blob", "hits", "legs_file")
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "batches_per_launch",
+                  "avg_launch_ms", "algorithmic_bytes_per_launch", "hbm_GBps_from_traffic", "wire_frac_of_peak")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "partition", "runs", "sample_GB", "algorithmic_GBps", "timed_while")
+_CONFIG_KEYS = ("workload", "batches", "queries", "query_len", "k", "num_hashes", "threshold", "nb_best_hits", "rows_divisor",
+                "sharding", "scan_mode", "pipeline_depth")
+
+
+def _clip(text, n):
+    return text if text is None or len(text) <= n else text[:n - 3] + "..."
+
+
+def _sig(x, digits=7):
+    """floats of the line carry 7 significant digits (the legs file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(full, legs_file=None):
+    """the driver-facing line of a full bench record: the contract's keys + roofline + roofline_narrow + cpu_baseline +
+    condensed participants, nothing else.  Pure function of the record (tests/test_golden_cpu.py runs it on recorded ones)."""
+    def pick(d, keys):
+        return None if d is None else {k: d[k] for k in keys if k in d}
+    line = {k: full.get(k) for k in LINE_KEYS if k in full}
+    cfg = pick(full.get("config"), _CONFIG_KEYS) or {}
+    cfg["workload"] = _clip(cfg.get("workload"), 240)
+    cfg["scan_mode"] = (full.get("scan_mode") or "").split(":")[0] or None
+    two = (full.get("config") or {}).get("batches_on_two_ranks")
+    if two:
+        cfg["batches_on_two_ranks"] = len(two)
+    line["config"] = cfg
+    for k in ("roofline", "roofline_narrow"):
+        r = pick(full.get(k), _ROOFLINE_KEYS)
+        if r is not None and r.get("traffic") is None and (full.get(k) or {}).get("traffic_note"):
+            r["traffic_note"] = _clip(full[k]["traffic_note"], 200)
+        line[k] = r
+    cb = pick(full.get("cpu_baseline"), _CPU_KEYS)
+    if cb is not None:
+        cb["sample"] = _clip(cb.get("sample"), 320)
+    line["cpu_baseline"] = cb
+    line["gpu_over_cpu"] = full.get("gpu_over_cpu")
+    p = full.get("participants") or {}
+    line["participants"] = {"ranks": p.get("ranks", len(p.get("rank_ms_per_step", [])) or 1), "backend": p.get("backend"),
+                            "rccl_ranks": p.get("rccl_ranks"),
+                            "rank_ms_per_step": [round(v, 3) for v in p.get("rank_ms_per_step", [])],
+                            "rank_devices": p.get("rank_devices"), "rank_batches": p.get("rank_batches")}
+    line["legs_file"] = legs_file
+    line = _sig(line)
+    line["value"] = full.get("value")                       # the headline keeps every digit
+    line["ms_per_step"] = full.get("ms_per_step")
+    return line
+
+
+def emit(full, legs_path, log=None):
+    """writes the whole record to `legs_path` (atomically, BEFORE the line), then prints the compact line as the last thing
+    on stdout.  A legs file that cannot be written costs the side file, never the line."""
+    written = None
+    if legs_path:
+        tmp = f"{legs_path}.{os.getpid()}.tmp"
+        try:
+            with open(tmp, "w") as f:
+                json.dump(full, f, allow_nan=False)
+                f.write("\n")
+            os.replace(tmp, legs_path)
+            written = os.path.abspath(legs_path)
+        except (OSError, ValueError) as e:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            if log:
+                log(f"[bench] legs file {legs_path!r} not written: {e!r}")
+    text = json.dumps(compact_line(full, written), allow_nan=False)
+    if len(text) > LINE_MAX_BYTES:                          # cannot happen with the clipped fields; never print an oversized line
+        raise RuntimeError(f"bench line is {len(text)} bytes (cap {LINE_MAX_BYTES})")
+    flush_c_stdio()
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
+    return text
+
+
 def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
     """Times oracle/cobs_oracle.c (kind "port": a restatement of the cobs classic search, NOT bioconda
     cobs 0.2.1) on the host cores, as SURVEY.md 8d / BASELINE.md section 2 specify it: index fully in
@@ -133,10 +227,10 @@ def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
         "host": f"{os.cpu_count()} logical CPUs visible, {cores} usable (affinity / cgroup quota): {cores} threads; "
                 f"{mem:.0f} GB of host RAM available to the job",
         "sample_GB": sample_bytes / 1e9,
-        "sample": (f"{nq} of the same queries x all {len(shapes)} batch shapes with rows/{div}: {sample_bytes / 1e9:.1f} GB of "
-                   f"signatures resident in host RAM (DRAM-resident: the matrices are {sample_bytes / 2.56e8 / 2:.0f} x the host's "
-                   f"2 x 256 MB of L3), median of 3 runs per partition, {sum(sum(v) for v in runs.values()):.0f} s of timed CPU work; "
-                   f"oracle/cobs_oracle.c COBS-restatement (not bioconda cobs 0.2.1), index in RAM like --load-complete"),
+        "sample": (f"{nq} of the same queries x all {len(shapes)} batch shapes at rows/{div}: {sample_bytes / 1e9:.1f} GB of signatures in "
+                   f"host RAM (DRAM-resident, like --load-complete), median of 3 runs x 2 partitions, "
+                   f"{sum(sum(v) for v in runs.values()):.0f} s of timed CPU work; oracle/cobs_oracle.c (restatement, not bioconda cobs 0.2.1)"),
+        "sample_vs_cache": f"the matrices are {sample_bytes / 2.56e8 / 2:.0f} x the host's 2 x 256 MB of L3",
         "algorithmic_GBps": alg / med[best] / 1e9,
     }
 
@@ -184,6 +278,12 @@ def main():
                          "partition; the column-slab partition runs ~2.5 x longer, so 16 gives about 25 s of timed CPU work")
     ap.add_argument("--cpu-sample-gb", type=float, default=0.0,
                     help="host-RAM size of the CPU baseline's index sample (0 = min(48 GB, 35 %% of the RAM available to the job))")
+    ap.add_argument("--legs-out", default="bench_legs.json",
+                    help="side file for the WHOLE record (the stdout line + every auxiliary leg: threshold_bound, unique_rows, "
+                         "argannot, clustered, l31, full_shard, full_collection, per-launch / per-rank detail); '' = none")
+    ap.add_argument("--whole-record", action="store_true",
+                    help="developer tooling (tools/*.sh): print the WHOLE record as the stdout line instead of the compact one; "
+                         "never what the driver runs -- the default line is capped at LINE_MAX_BYTES")
     ap.add_argument("--dump-hits", default=None, help="rank 0 saves the ordered hit records of the headline mode (.npy)")
     ap.add_argument("--dump-full-hits", default=None, help="rank 0 saves the records of the full_collection leg (N >= 8 ranks) (.npy)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -447,9 +547,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
             if world > 1 or args.emulate_world:
-                return None, (f"the PMC passes (profiles/pmc_traffic.json) were collected on the 1-rank launch that covers all "
-                              f"{len(shapes)} batches; a rank of {nparts} launches over its own shard only, so the per-launch figure "
-                              "does not transfer (1-rank ratio traffic / algorithmic: see the N = 1 line)")
+                return None, (f"PMC passes were collected on the 1-rank launch over all {len(shapes)} batches (profiles/pmc_traffic.json); "
+                              f"a rank of {nparts} scans its own shard only, so the per-launch figure does not transfer")
             tj = json.load(open(tpath))
             if tj.get("pm_kernels_blob") != blob:
                 return None, f"profiles/pmc_traffic.json was measured on pm_kernels.hip blob {str(tj.get('pm_kernels_blob'))[:12]}, this is {blob[:12]}: re-run tools/run_pmc.sh"
@@ -978,8 +1077,11 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if ok and rank == 0:
-        flush_c_stdio()
-        print(json.dumps(out), flush=True)
+        if args.whole_record:
+            flush_c_stdio()
+            print(json.dumps(out, allow_nan=False), flush=True)
+        else:
+            emit(out, args.legs_out, log)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -213,13 +213,13 @@ def make_queries(n, length=150, seed=31):
     return b"".join(parts), seqs
 
 
-_ARGANNOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "argannot", "lengths.txt")
+_ARGANNOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "argannot_lengths.txt")
 
 
 def argannot_lengths(path=_ARGANNOT):
     """sequence lengths of the 1 856 records of the reference's data/ARGannot_r3.fa in file order (SURVEY.md 8d's third
-    query shape: genes of 237 ... 3 153 bp, 1 594 532 31-mers); the committed fixture is lengths only
-    (tools/gen_golden_argannot.py)"""
+    query shape: genes of 237 ... 3 153 bp, 1 594 532 31-mers); package data, lengths only
+    (written by tools/gen_golden_argannot.py; tests/test_golden_cpu.py re-derives it from the reference when that is present)"""
     with open(path) as f:
         return [int(x) for x in f if x.strip() and not x.startswith("#")]
 

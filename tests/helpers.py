@@ -84,3 +84,50 @@ def sample_reads(rng, strains, n_reads, read_len=150, error=0.01):
         p = int(rng.integers(0, len(s) - read_len))
         out.append((d, codes_to_seq(mutate(rng, s[p:p + read_len], error)).decode()))
     return out
+
+
+# ---------------------------------------------------------------- bench.py's driver-facing line
+BENCH_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                   "vs_baseline", "dtype", "data", "config", "roofline", "roofline_narrow", "cpu_baseline", "gpu_over_cpu",
+                   "participants", "pm_kernels_blob", "legs_file")
+BENCH_LEG_KEYS = ("threshold_bound", "unique_rows", "argannot", "clustered", "l31", "full_shard", "full_collection",
+                  "scan_launches", "rank0_ms", "value_note")
+
+
+def check_bench_line(text):
+    """What the round-5 driver record lost (BENCH_r05.json "parsed": null after the line grew to 28.6 KB): the last
+    stdout line of bench.py is ONE small strict-JSON object with the contract's keys and none of the auxiliary legs."""
+    import json
+
+    def no_constants(name):
+        raise AssertionError(f"non-strict JSON constant {name} in the bench line")
+    assert "\n" not in text and len(text.encode()) < 8192, len(text)
+    line = json.loads(text, parse_constant=no_constants)
+    assert isinstance(line, dict)
+    missing = [k for k in BENCH_LINE_KEYS if k not in line]
+    assert not missing, missing
+    assert not [k for k in BENCH_LEG_KEYS if k in line]
+    assert isinstance(line["config"], dict) and isinstance(line["config"].get("workload"), str) and "model" not in line["config"]
+    assert line["unit"] == "k-mers/s" and line["higher_is_better"] is True and line["data"] == "synthetic"
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    part = line["participants"]
+    assert part["ranks"] == line["n_gpus"] == len(part["rank_ms_per_step"])
+    return line
+
+
+def bench_record(stdout_bytes, legs_path):
+    """(line, whole record) of one bench.py run: the LAST stdout line, checked, and the --legs-out side file"""
+    import json
+    out = stdout_bytes.decode()
+    assert out.endswith("\n") and out.count("\n{") + out.startswith("{") == 1, out[-400:]      # one JSON line, nothing behind it
+    line = check_bench_line(out.rstrip("\n").splitlines()[-1])
+    full = json.load(open(legs_path))
+    import os
+    assert os.path.realpath(line["legs_file"]) == os.path.realpath(str(legs_path))
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup"):
+        assert full[k] == line[k], k
+    return line, full

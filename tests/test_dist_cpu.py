@@ -417,6 +417,22 @@ def test_self_launched_ranks_rendezvous_on_the_port_the_launcher_holds(tmp_path)
     assert (tmp_path / "sum0").read_text() == "3" and (tmp_path / "sum1").read_text() == "3"
 
 
+def test_gene_length_package_data_is_what_the_generator_writes(tmp_path):
+    """phylign_amd/data/argannot_lengths.txt is package data (bench.py and an installed package need no tests/ tree); it is
+    byte for byte what tools/gen_golden_argannot.py derives from the reference's data/ARGannot_r3.fa (build container only)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.dirname(os.path.abspath(W._ARGANNOT)) == os.path.join(root, "phylign_amd", "data") and os.path.exists(W._ARGANNOT)
+    ref = "/root/reference/data/ARGannot_r3.fa"
+    if not os.path.exists(ref):
+        pytest.skip("the reference checkout is not on this machine")
+    out = tmp_path / "lengths.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_golden_argannot.py"), ref, str(out)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == open(W._ARGANNOT, "rb").read()
+
+
 def test_gene_length_workload_helpers():
     """the query shape of the reference's bundled gene file: the committed lengths fixture, the ragged query
     maker and the ragged planting plan (fractions that straddle the threshold, per-query k-mer counts)"""

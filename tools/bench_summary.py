@@ -1,9 +1,17 @@
 #!/usr/bin/env python3
-"""prints the figures of a bench line that the round's notes quote: python tools/bench_summary.py <bench.json>"""
+"""prints the figures of a bench record that the round's notes quote: python tools/bench_summary.py <bench.json>
+<bench.json> is either the side file of a run (bench.py --legs-out: the whole record) or the stdout line, whose
+`legs_file` names the side file (looked up as written, then by its base name next to the line's file)."""
 import json
+import os
 import sys
 
-d = json.load(open(sys.argv[1]))
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+if d.get("legs_file") and "scan_launches" not in d:
+    for cand in (d["legs_file"], os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), os.path.basename(d["legs_file"]))):
+        if os.path.exists(cand):
+            d = json.load(open(cand))
+            break
 print("value %.4g k-mers/s  %.3f ms/step  roofline frac %.3f (%.2f ms)  n_gpus %d" % (
     d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["n_gpus"]))
 if d.get("threshold_bound"):

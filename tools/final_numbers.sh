@@ -5,5 +5,5 @@ set -u
 tag=${1:-r03}
 out=gpurun_out/final_$tag
 mkdir -p $out
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1_driver_flags.json 2> $out/bench.log; echo "bench rc=$?"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --legs-out $out/bench_n1_driver_flags_legs.json > $out/bench_n1_driver_flags.json 2> $out/bench.log; echo "bench rc=$?"
 bash tools/e2e_numbers.sh $out

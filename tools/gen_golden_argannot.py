@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """The query SHAPE of the reference's bundled gene file (data/ARGannot_r3.fa): one line per record,
 `<sequence length>` in file order -- data only, no sequence and no header text.  Run in the build container
-(needs /root/reference); tests and bench.py read the committed tests/golden/argannot/lengths.txt."""
+(needs /root/reference); bench.py and the tests read the committed phylign_amd/data/argannot_lengths.txt
+(workload.argannot_lengths).    python3 tools/gen_golden_argannot.py [<ARGannot_r3.fa> [<out file>]]"""
 import os
 import sys
 
 ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/data/ARGannot_r3.fa"
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "argannot", "lengths.txt")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "phylign_amd", "data",
+                                                        "argannot_lengths.txt")
 lens, cur = [], None
 with open(ref) as f:
     for line in f:

@@ -163,6 +163,11 @@ size_t parallel_width();                    // worker threads + the caller (<= 1
 // pm_index.cpp: pooled staging buffers of the parallel file loader (released by pm_shutdown)
 void release_stage_pool();
 void release_query_pool();                   // pm_queries.cpp: device buffers of released query sets
+void release_hit_pool();                     // pm_search.cpp: pooled device hit buffers of finished searches
+// pm_runtime.cpp: hipMalloc that gives the library's OWN idle HBM back before it reports out-of-memory: the pools of
+// query-set buffers and hit buffers hold memory the stage budget does not count (up to 16 + 8 buffers); a signature
+// matrix or a hit buffer that does not fit next to them gets one more try after they were released
+hipError_t device_malloc_reclaim(void** out, size_t bytes);
 int query_buf_take(size_t bytes, void** out);   // a device buffer of a query set (pooled; given back by pm_queries_release_device)
 void release_text_pool();                    // pm_text.cpp: the pooled text / gzip buffers of the 03_match writer
 // pm_gzfast.cpp: text[0, n) (n < 2^31) as one gzip member -- fixed-Huffman deflate, line-structured matches -- written

@@ -2,6 +2,7 @@
 // readers, streaming upload with re-striding, synthetic 661k-shaped indexes, planted content.
 #include "pm_host.h"
 #include <chrono>
+#include <ctime>
 
 // ---------------------------------------------------- classic index header
 // "COBS:" "CLASSIC_INDEX" u32 version, then the fields, the newline-terminated
@@ -108,7 +109,7 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     ix->g = (int)pow2ceil(lanes);
     ix->slabs = (uint32_t)((stride + 1023) / 1024);
     const auto t_m0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc((void**)&ix->d_matrix, in.device_bytes);
+    hipError_t e = device_malloc_reclaim((void**)&ix->d_matrix, in.device_bytes);   // idle pooled buffers go first
     if (getenv("PM_LOAD_TRACE"))
         fprintf(stderr, "[pm_load] hipMalloc %.2f GB: %.1f ms\n", in.device_bytes / 1e9,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_m0).count());
@@ -485,7 +486,7 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
             part->g = (int)pow2ceil((std::min<uint64_t>(stride, 1024) + 15) / 16);
             part->slabs = (uint32_t)((stride + 1023) / 1024);
             rc = check_matrix_size(pc.sig[p], sa);
-            hipError_t e = rc ? hipSuccess : hipMalloc((void**)&part->d_matrix, in.device_bytes);
+            hipError_t e = rc ? hipSuccess : device_malloc_reclaim((void**)&part->d_matrix, in.device_bytes);
             if (rc) {}
             else if (e != hipSuccess || !part->d_matrix) {
                 part->d_matrix = nullptr;
@@ -511,21 +512,32 @@ extern "C" int pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index
 } PM_GUARD_END
 // The decode-once cache of a compressed index (the reference's `mem-disk` mode with
 // keep_cobs_indexes, Snakefile:364-387): while the stream (`xzcat` pipe) is loaded into HBM every byte read is also
-// written to a temporary file of this call's own ("<tee_path>.XXXXXX.tmp", mkstemps: two processes decoding the same
-// batch into one cache directory never share an inode), which becomes `tee_path` once the whole index has arrived and
-// the file on disk has exactly the bytes that were read -- a later run finds the plain file and takes the parallel pread
-// path instead of decoding again.  When another process published the same index first, this call's copy is dropped.  A
-// failed load leaves no file behind; a failed WRITE (disk full) does not fail the load: the index is resident, only
-// the cache file is dropped (*cached = 0).
+// written to a file of this call's own, which becomes `tee_path` once the whole index has arrived and the file on
+// disk has exactly the bytes that were read -- a later run finds the plain file and takes the parallel pread path
+// instead of decoding again.  The file is an UNNAMED inode of the cache directory (O_TMPFILE) for as long as it is
+// incomplete: a stage that is killed mid-load (SIGKILL from the launcher's grace period, the OOM killer) leaves nothing
+// behind, however many GB it had written.  Publishing = linkat() to "<tee_path>.XXXXXX.tmp" + rename() over `tee_path`
+// (two processes decoding the same batch never share an inode; when another one published the same index first, this
+// call's copy is dropped).  On a file system without O_TMPFILE the same name is created up front with mkstemps and
+// unlinked on every failing return.  A failed load leaves no file; a failed WRITE (disk full) does not fail the load: the
+// index is resident, only the cache file is dropped (*cached = 0).
 extern "C" int pm_index_load_fd_tee(int fd, uint64_t size_hint, int layout, const char* tee_path, int* cached, pm_index_t** out) try {
     NEED_DEV();
     if (!out || fd < 0 || !tee_path) return fail(PM_EINVAL, "bad argument");
     if (cached) *cached = 0;
     std::string tmp = std::string(tee_path) + ".XXXXXX.tmp";
+    std::string dir = tee_path;
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : dir.substr(0, slash));
     Reader rd; rd.fd = fd;
-    rd.tee_fd = mkstemps(&tmp[0], 4);                          // O_CREAT | O_EXCL, a name of this call's own
-    if (rd.tee_fd < 0) rd.tee_errno = errno;                  // no cache file: the load itself goes on
-    else (void)fchmod(rd.tee_fd, 0644);
+    bool named = false;                                       // `tmp` exists under its name (mkstemps fallback)
+    rd.tee_fd = open(dir.c_str(), O_TMPFILE | O_WRONLY | O_CLOEXEC, 0644);
+    if (rd.tee_fd >= 0) (void)fchmod(rd.tee_fd, 0644);        // whatever the umask: the cache is read by later runs of any user
+    else {
+        rd.tee_fd = mkstemps(&tmp[0], 4);                      // O_CREAT | O_EXCL, a name of this call's own
+        if (rd.tee_fd < 0) rd.tee_errno = errno;              // no cache file: the load itself goes on
+        else { named = true; (void)fchmod(rd.tee_fd, 0644); }
+    }
     int rc = load_from_reader(rd, size_hint, layout, false, out);
     bool ok = rc == PM_OK && rd.tee_fd >= 0 && !rd.tee_errno;
     if (ok) {
@@ -535,13 +547,27 @@ extern "C" int pm_index_load_fd_tee(int fd, uint64_t size_hint, int layout, cons
         ok = in.n_parts == 0 && rd.tee_bytes >= in.signature_size * in.row_bytes &&
              fstat(rd.tee_fd, &sb) == 0 && (uint64_t)sb.st_size == rd.tee_bytes;
     }
+    if (ok && !named) {
+        // give the finished inode its (unique) name; the descriptor stays open until the link exists
+        char self[64];
+        snprintf(self, sizeof self, "/proc/self/fd/%d", rd.tee_fd);
+        ok = false;
+        for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
+            std::string cand = std::string(tee_path) + ".XXXXXX.tmp";
+            static const char al[] = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789";
+            uint64_t r = ((uint64_t)getpid() << 32) ^ (uint64_t)(uintptr_t)&rd ^ ((uint64_t)attempt * 0x9E3779B97F4A7C15ull) ^ (uint64_t)time(nullptr);
+            for (size_t i = cand.size() - 10; i < cand.size() - 4; ++i) { r = r * 6364136223846793005ull + 1442695040888963407ull; cand[i] = al[(r >> 33) % 62]; }
+            if (linkat(AT_FDCWD, self, AT_FDCWD, cand.c_str(), AT_SYMLINK_FOLLOW) == 0) { tmp = cand; named = true; ok = true; }
+            else if (errno != EEXIST) break;
+        }
+    }
     if (rd.tee_fd >= 0) { if (close(rd.tee_fd) != 0) ok = false; }
     if (ok) {
         struct stat sb;
         if (stat(tee_path, &sb) == 0 && (uint64_t)sb.st_size == rd.tee_bytes) (void)unlink(tmp.c_str());   // published by another process meanwhile
         else if (rename(tmp.c_str(), tee_path) != 0) ok = false;
     }
-    if (!ok && rd.tee_fd >= 0) (void)unlink(tmp.c_str());
+    if (!ok && named) (void)unlink(tmp.c_str());
     if (cached) *cached = ok ? 1 : 0;
     return rc;
 } PM_GUARD_END

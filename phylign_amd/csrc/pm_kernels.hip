@@ -253,6 +253,9 @@ __device__ __forceinline__ u32x4 ld_row(const uint8_t* p) {
 #ifndef PM_SCAN_SHARE_ROWS
 #define PM_SCAN_SHARE_ROWS 1         // lanes of a group split the row-offset computation of a step (G >= 8, one hash)
 #endif
+#ifndef PM_SCAN_SHARE_MAX_P
+#define PM_SCAN_SHARE_MAX_P 13       // widest counter class that shares (7: round 5's setting)
+#endif
 #ifndef PM_SCAN_MIN_WAVES
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
@@ -376,38 +379,35 @@ __global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
         u32x4 x[TS];
 #pragma unroll
         for (int i = 0; i < TS; ++i) x[i] = (u32x4)(0u);
-        // The lanes of a group all need the same TS row offsets.  With 8+ lanes per group and one hash
-        // function each lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett
-        // reduction instead of TS of each) and the group shares the offsets by ds_bpermute; every lane
-        // takes part in the exchange, alive or not (a disabled source lane would deliver 0).
-        // (only the 7-plane class of reads: the eight 64-bit offsets cost 16 registers, which the wider counter
-        // classes do not have to spare)
-        constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8 && P <= 7;
-        uint32_t my_lo = 0, my_hi = 0;
+        // The lanes of a group all need the same TS rows.  With 8+ lanes per group and one hash function each
+        // lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett reduction instead of TS
+        // of each) and the group shares the ROW INDICES by ds_bpermute; every lane takes part in the exchange,
+        // alive or not (a disabled source lane would deliver 0).  A row index fits 32 bits here: G >= 8 means
+        // a stride of at least 128 bytes, and rows x stride is resident in HBM (pm_index.cpp checks it against
+        // the device's memory), so rows < 309 GB / 128 B < 2^32.  One exchanged register per k-mer, consumed by
+        // (the byte offset is one v_mad_u64_u32 per lane): 8 registers instead of the 16 that round 5's exchange
+        // of 64-bit offsets took, which is what lets the 10- and 13-plane classes (40 / 52 plane registers)
+        // share as well.
+        constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8 && P <= PM_SCAN_SHARE_MAX_P;
+        uint32_t my_row = 0;
         if constexpr (SHARE) {
             const uint32_t i_mine = c & (uint32_t)(TS - 1);
-            if (qv && t0i + i_mine < nt) {
-                const uint64_t hm = a.hashes[(pb + b) * 8 + i_mine];         // [blk][hash 0][8]
-                const uint64_t off = mod_sig(hm, S, bm) * stride;
-                my_lo = (uint32_t)off; my_hi = (uint32_t)(off >> 32);
-            }
+            if (qv && t0i + i_mine < nt)
+                my_row = (uint32_t)mod_sig(a.hashes[(pb + b) * 8 + i_mine], S, bm);      // [blk][hash 0][8]
         }
-        uint64_t roff[SHARE ? TS : 1];
+        const bool go = active && t0i < nt && line_alive;
+        const uint32_t left = go ? nt - t0i : 0u;         // valid k-mers of this step for this lane (0: no gather)
+        if (a.fetch_count) nfetch += (left < (uint32_t)TS ? left : (uint32_t)TS) * nh;
+        uint32_t rows[SHARE ? TS : 1];
         if constexpr (SHARE) {
 #pragma unroll
-            for (int i = 0; i < TS; ++i) {
-                const uint32_t lo_ = (uint32_t)__shfl((int)my_lo, (int)(gfirst0 + (uint32_t)i), 64);
-                const uint32_t hi_ = (uint32_t)__shfl((int)my_hi, (int)(gfirst0 + (uint32_t)i), 64);
-                roff[i] = ((uint64_t)hi_ << 32) | lo_;
-            }
+            for (int i = 0; i < TS; ++i) rows[i] = (uint32_t)__shfl((int)my_row, (int)(gfirst0 + (uint32_t)i), 64);
         }
-        if (active && t0i < nt && line_alive) {
-            const uint32_t left = nt - t0i;           // >= 1 valid terms in this step
-            if (a.fetch_count) nfetch += (left < (uint32_t)TS ? left : (uint32_t)TS) * nh;
+        if (go) {
             if constexpr (SHARE) {
 #pragma unroll
                 for (int i = 0; i < TS; ++i)
-                    if ((uint32_t)i < left) x[i] = ld_row(base + roff[i]);
+                    if ((uint32_t)i < left) x[i] = ld_row(base + (uint64_t)rows[i] * stride);
             } else
             for (uint32_t j = 0; j < nh; ++j) {
                 const u32x4* hj = hp + (size_t)(b * nh + j) * 4 + (sidx % SPB) * (TS / 2);

@@ -372,11 +372,7 @@ int query_buf_take(size_t bytes, void** out) {
             return PM_OK;
         }
     }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory) {                     // what waits in the pool may be what is missing
-        release_query_pool();
-        e = hipMalloc(out, bytes);
-    }
+    const hipError_t e = device_malloc_reclaim(out, bytes);          // out of memory: the pools are emptied, one more try
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "hipMalloc(%zu bytes) for a query set: %s", bytes, hipGetErrorString(e));
     return PM_OK;
 }

@@ -155,10 +155,22 @@ extern "C" void pm_shutdown(void) {
     release_stage_pool();
     release_text_pool();
     release_query_pool();
-    for (auto& b : g_ctx.free_hits) (void)hipFree(b.p);
+    release_hit_pool();
     if (g_ctx.d_fetch) (void)hipFree(g_ctx.d_fetch);
     for (auto& b : g_ctx.free_pinned) (void)hipHostFree(b.p);
     g_ctx = Ctx();
+}
+
+hipError_t device_malloc_reclaim(void** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();                 // the failed attempt must not be what a later hipGetLastError() reports
+        release_query_pool();
+        release_hit_pool();
+        e = hipMalloc(out, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    return e;
 }
 
 extern "C" int pm_device_info(char* name, size_t cap, uint64_t* hbm_total, uint64_t* hbm_free, int* n_cus) try {

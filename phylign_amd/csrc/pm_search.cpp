@@ -44,8 +44,18 @@ static int take_hit_buffer(uint64_t cap, HitBuf* out) {
     }
     out->cap = cap;
     // `cap` records followed by the run directory (a run holds at least two records)
-    HIPCHK(hipMalloc((void**)&out->p, (cap + run_cap_of(cap)) * sizeof(uint4)));
+    const hipError_t e = device_malloc_reclaim((void**)&out->p, (cap + run_cap_of(cap)) * sizeof(uint4));
+    if (e != hipSuccess) {
+        out->p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP, "hipMalloc(%zu bytes) for a hit buffer: %s",
+                    (size_t)((cap + run_cap_of(cap)) * sizeof(uint4)), hipGetErrorString(e));
+    }
     return PM_OK;
+}
+void release_hit_pool() {
+    std::vector<HitBuf> all;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); all.swap(g_ctx.free_hits); }
+    for (auto& b : all) (void)hipFree(b.p);
 }
 static void give_hit_buffer(HitBuf b) {
     if (!b.p) return;

@@ -63,6 +63,7 @@ class IndexCache:
         self.items = OrderedDict()          # key -> {"ix", "bytes", "users", "ready": Event, "error"}
         self.mu = threading.Condition()
         self.loads = self.hits = self.waits = 0
+        self.cold_active = 0                # .xz loads being decoded right now (they share the host's CPUs)
 
     def used(self):
         return sum(e["bytes"] for e in self.items.values())
@@ -116,10 +117,11 @@ class IndexCache:
                 from . import xzpar
                 from .sysinfo import effective_cpus
                 with self.mu:
-                    self.cold_active = getattr(self, "cold_active", 0) + 1
+                    self.cold_active += 1
                     threads = int(os.environ.get("PHYLIGN_XZ_THREADS", "0")) or max(1, min(8, effective_cpus() // self.cold_active))
                 try:
-                    pl = xzpar.plan(path) if threads > 1 else None
+                    # (plan() never opens anything but a regular file: a pipe named *.xz goes to xzcat with its header intact)
+                    pl = xzpar.plan(path) if threads > 1 and stat.S_ISREG(st.st_mode) else None
                     if pl is not None:
                         p = xzpar.ParallelXz(pl, min(threads, len(pl.blocks)))
                     else:

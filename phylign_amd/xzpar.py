@@ -11,13 +11,15 @@ absent, so this module reads the container itself (stream footer -> index ->
 block offsets, per block: header -> LZMA2 dictionary size) and hands every
 block's raw LZMA2 data to Python's `lzma` module, which releases the GIL while
 it decodes.  Anything it does not understand -- several streams, other filters
-than one LZMA2, a single block -- makes `plan()` return None and the caller
-falls back to `xzcat`.
+than one LZMA2 (checked on EVERY block header, not only the index), a single
+block, a path that is not a regular file -- makes `plan()` return None and the
+caller falls back to `xzcat`.
 
 Container layout: the .xz file format specification 1.0.4, sections 2.1 (stream
 header / footer), 3.1 (block header), 4 (index)."""
 import lzma
 import os
+import stat
 import struct
 import threading
 import zlib
@@ -50,7 +52,12 @@ def _varint(buf, pos):
 def plan(path, min_blocks=2):
     """Block table of a single-stream .xz file whose blocks can be decoded independently, or None (then use xzcat)."""
     try:
-        size = os.path.getsize(path)
+        st = os.stat(path)
+        if not stat.S_ISREG(st.st_mode):
+            return None                                      # a pipe / device: never opened here (reading would eat its header)
+        size = st.st_size
+        if size < 32:
+            return None
         with open(path, "rb") as f:
             head = f.read(12)
             if size < 32 or head[:6] != _HEADER_MAGIC or zlib.crc32(head[6:8]) != struct.unpack("<I", head[8:12])[0]:
@@ -85,17 +92,38 @@ def plan(path, min_blocks=2):
             total += uncomp
         if off != size - 12 - index_size:
             return None                                      # blocks + index + footer must be the whole file (one stream)
+        # every block must be what _decode_block handles (one LZMA2 filter): a file written with, say, --delta or --x86 in
+        # front of LZMA2 has a perfectly good index, and finding that out in a worker would abort a load xzcat can do
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            for blk in blocks:
+                _block_header(_pread_all(fd, min(1024, blk.unpadded_size), blk.offset), blk.unpadded_size)
+        finally:
+            os.close(fd)
         return Plan(path, blocks, check_size, total)
     except (OSError, ValueError, IndexError, struct.error):
         return None
 
 
-def _decode_block(fd, blk, check_size):
-    raw = os.pread(fd, blk.unpadded_size, blk.offset)
-    if len(raw) != blk.unpadded_size or raw[0] == 0:
-        raise ValueError("short read or index indicator where a block header should be")
+def _pread_all(fd, n, offset):
+    """n bytes at offset; one os.pread returns at most 2 GiB - 4 KiB on Linux, a block may be larger"""
+    parts, got = [], 0
+    while got < n:
+        part = os.pread(fd, min(n - got, 1 << 30), offset + got)
+        if not part:
+            raise ValueError("short read: the file ends inside a block")
+        parts.append(part)
+        got += len(part)
+    return parts[0] if len(parts) == 1 else b"".join(parts)
+
+
+def _block_header(raw, unpadded_size):
+    """(header size, LZMA2 dictionary size) of the block header at raw[0:] (spec 3.1); ValueError for anything but ONE
+    LZMA2 filter with its one properties byte"""
+    if not raw or raw[0] == 0:
+        raise ValueError("index indicator where a block header should be")
     hsize = (raw[0] + 1) * 4
-    if hsize > len(raw) or zlib.crc32(raw[:hsize - 4]) != struct.unpack("<I", raw[hsize - 4:hsize])[0]:
+    if hsize > len(raw) or hsize > unpadded_size or zlib.crc32(raw[:hsize - 4]) != struct.unpack("<I", raw[hsize - 4:hsize])[0]:
         raise ValueError("block header CRC mismatch")
     flags = raw[1]
     if flags & 0x3C or (flags & 3) != 0:
@@ -107,12 +135,17 @@ def _decode_block(fd, blk, check_size):
         _, pos = _varint(raw, pos)
     fid, pos = _varint(raw, pos)
     psize, pos = _varint(raw, pos)
-    if fid != 0x21 or psize != 1:
+    if fid != 0x21 or psize != 1 or pos >= hsize - 4:
         raise ValueError("block is not plain LZMA2")
     bits = raw[pos] & 0x3F
     if bits > 40:
         raise ValueError("bad LZMA2 dictionary size")
-    dict_size = 0xFFFFFFFF if bits == 40 else (2 | (bits & 1)) << (bits // 2 + 11)
+    return hsize, (0xFFFFFFFF if bits == 40 else (2 | (bits & 1)) << (bits // 2 + 11))
+
+
+def _decode_block(fd, blk, check_size):
+    raw = _pread_all(fd, blk.unpadded_size, blk.offset)
+    hsize, dict_size = _block_header(raw, blk.unpadded_size)
     dec = lzma.LZMADecompressor(format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": dict_size}])
     out = dec.decompress(raw[hsize:len(raw) - check_size])
     if len(out) != blk.uncompressed_size:

@@ -1490,3 +1490,57 @@ def test_block_parallel_xz_decoder_equals_xzcat(tmp_path):
     p.stdout.read(1000)
     p.stdout.close()
     assert p.wait() == 1
+
+
+def test_block_parallel_xz_plan_refuses_what_only_xzcat_can_decode(tmp_path):
+    """a VALID multi-block .xz whose blocks are not plain LZMA2 (`--delta` in front of it) has a perfectly good
+    index; plan() reads every block header and returns None, so the caller streams the file through xzcat instead of
+    aborting the load.  A path that is not a regular file (a FIFO named *.xz) is never opened by plan()."""
+    import subprocess
+    import threading
+    from phylign_amd import match_stage as MS
+    from phylign_amd import xzpar
+    rng = np.random.default_rng(13)
+    data = bytes(rng.integers(0, 7, 3_000_001, dtype=np.uint8))
+    src = tmp_path / "d.bin"
+    src.write_bytes(data)
+    delta, plain = tmp_path / "delta.xz", tmp_path / "plain.xz"
+    with open(delta, "wb") as f:
+        subprocess.run(["xz", "-T2", "--block-size=1MiB", "--delta=dist=1", "--lzma2=preset=0", "-c", str(src)], stdout=f, check=True)
+    with open(plain, "wb") as f:
+        subprocess.run(["xz", "-T2", "--block-size=1MiB", "-0", "-c", str(src)], stdout=f, check=True)
+    assert subprocess.run(["xzcat", str(delta)], capture_output=True, check=True).stdout == data      # a valid file ...
+    assert xzpar.plan(str(delta)) is None                                                                # ... that only xzcat decodes
+    pl = xzpar.plan(str(plain))
+    assert pl is not None and len(pl.blocks) == 3
+    # the stage's stream opener falls back to xzcat for it and delivers every byte
+    cobs = tmp_path / "cobs"
+    cobs.mkdir()
+    os.link(delta, cobs / "bdelta.cobs_classic.xz")
+    os.link(plain, cobs / "bplain.cobs_classic.xz")
+    for batch, kind in (("bdelta", "Popen"), ("bplain", "ParallelXz")):
+        f, dec = MS.open_index_stream(str(cobs), batch, xz_threads=4)
+        assert type(dec).__name__ == kind
+        assert f.read() == data and dec.wait() == 0
+        f.close()
+    # one block header damaged in an otherwise well-formed file: no plan (xzcat then reports the damage itself)
+    blob = bytearray(plain.read_bytes())
+    blob[pl.blocks[1].offset + 1] ^= 0x03                     # block flags: claims more filters than the header holds
+    (tmp_path / "hdr.xz").write_bytes(bytes(blob))
+    assert xzpar.plan(str(tmp_path / "hdr.xz")) is None
+    # a FIFO: plan() must not read from it (it would eat the stream header in front of the real decoder)
+    fifo = tmp_path / "pipe.xz"
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: open(fifo, "wb").write(plain.read_bytes()), daemon=True)
+    assert xzpar.plan(str(fifo)) is None                      # returns at once: nothing was opened, no writer needed
+    t.start()
+    assert subprocess.run(["xzcat", str(fifo)], capture_output=True, check=True).stdout == data
+    t.join(10)
+    # blocks larger than one pread delivers are read in pieces
+    fd = os.open(str(src), os.O_RDONLY)
+    try:
+        assert xzpar._pread_all(fd, len(data), 0) == data and xzpar._pread_all(fd, 10, len(data) - 10) == data[-10:]
+        with pytest.raises(ValueError):
+            xzpar._pread_all(fd, 11, len(data) - 10)
+    finally:
+        os.close(fd)

@@ -721,6 +721,53 @@ def test_two_decoders_of_one_batch_share_a_cache_directory(pm, oracle, tmp_path)
         assert pm.query_text(ix, fasta, 0.7) == oracle.query_file(index, fasta, 0.7)
 
 
+def test_a_killed_cold_load_leaves_no_cache_temporary(pm, oracle, tmp_path):
+    """the decode-once cache file is an unnamed inode (O_TMPFILE) until it is complete, so a load that is
+    SIGKILLed half way -- the launcher's grace period, the OOM killer -- leaves nothing in the cache directory, whatever it
+    had written; a finished load publishes the plain file under its final name only"""
+    import signal
+    import time
+    rng = np.random.default_rng(4)
+    index, fasta, _ = build_case(oracle, rng, 664, 60000, [("q", rand_seq(rng, 150))])
+    blob = tmp_path / "whole.bin"
+    blob.write_bytes(bytes(index))
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    code = (
+        "import os, sys, time, threading\n"
+        "from phylign_amd import _lib as pm\n"
+        "pm.load(); pm.init(0)\n"
+        "blob = open(sys.argv[1], 'rb').read(); half = len(blob) // 2\n"
+        "r, w = os.pipe()\n"
+        "def feed():\n"
+        "    os.write(w, blob[:half])\n"
+        "    open(sys.argv[3], 'w').write('half')\n"
+        "    if sys.argv[4] == 'stall':\n"
+        "        time.sleep(600)\n"
+        "    with os.fdopen(w, 'wb') as f:\n"
+        "        f.write(blob[half:])\n"
+        "threading.Thread(target=feed, daemon=True).start()\n"
+        "ix = pm.Index.load_fd(r, size_hint=len(blob), tee_path=sys.argv[2])\n"
+        "print('cached', ix.cached)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    tee = cache / "b__01.cobs_classic"
+    flag = tmp_path / "half_written"
+    p = subprocess.Popen([sys.executable, "-c", code, str(blob), str(tee), str(flag), "stall"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0 = time.time()
+    while not flag.exists() and p.poll() is None and time.time() - t0 < 240:
+        time.sleep(0.05)
+    assert flag.exists() and p.poll() is None, p.stderr.read().decode()[-2000:]
+    time.sleep(0.5)                                             # the loader has consumed (and teed) what was written
+    p.send_signal(signal.SIGKILL)
+    p.wait()
+    assert list(cache.iterdir()) == []                          # nothing: not even a *.tmp
+    flag.unlink()
+    r = subprocess.run([sys.executable, "-c", code, str(blob), str(tee), str(flag), "go"], env=env, capture_output=True)
+    assert r.returncode == 0 and b"cached True" in r.stdout, r.stderr.decode()[-2000:]
+    assert [f.name for f in cache.iterdir()] == ["b__01.cobs_classic"] and tee.read_bytes() == blob.read_bytes()
+    assert oct(tee.stat().st_mode & 0o777) == "0o644"
+
+
 def test_match_stage_with_gene_length_queries(pm, oracle, tmp_path):
     """the reference's bundled gene file as a query set: every 8th record length of data/ARGannot_r3.fa
     (232 genes, 237 ... 3 150 bp: the 10- and 13-plane counter classes in one search) through the whole stage -- .xz

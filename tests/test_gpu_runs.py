@@ -574,3 +574,44 @@ def test_saved_index_file_is_the_resident_index(pm, oracle, tmp_path, n_docs, S,
     ix2 = pm.Index.load_file(path)
     assert _names(ix2) == _names(ix) and np.array_equal(np.asarray(ix2.read_rows(0, S)), np.asarray(ix.read_rows(0, S)))
     ix.free(); ix2.free()
+
+
+def test_index_allocation_reclaims_the_librarys_idle_pools(pm):
+    """device buffers of released query sets (and of finished searches) wait in pools the stage budget does not
+    count.  A signature matrix that only fits once they are given back is allocated all the same: the out-of-memory path
+    empties the pools and tries once more (device_malloc_reclaim, pm_runtime.cpp) instead of reporting PM_ENOMEM."""
+    from phylign_amd import workload as W
+    MB = 1 << 20
+    pm.set_option("release_query_pool", 1)
+    names = [f"d{i}" for i in range(4096)]                       # 512-byte rows in either layout
+    sets = []
+    for n in (300_000, 360_000, 420_000):                        # 288 + 346 + 403 MB of hashes, plus sequences and descriptors
+        fasta, _ = W.make_queries(n, 150, seed=n)
+        q = pm.Queries(fasta, term_size=31)
+        q.hash_terms(1, 1)                                       # uploads the set and hashes it on the device
+        sets.append(q)
+    held = sum(q.device_bytes()[0] for q in sets)
+    assert held > 1000 * MB
+    free_before = pm.device_info()["hbm_free"]
+    for q in sets:
+        q.release_device()                                       # -> pooled, not freed
+    free_pooled = pm.device_info()["hbm_free"]
+    assert free_pooled - free_before < held // 4                 # the pool still holds (most of) it
+    filler = pm.Index.create(names, (free_pooled - 300 * MB) // 512, layout=2)
+    left = pm.device_info()["hbm_free"]
+    assert left < 400 * MB
+    want = 900 * MB                                              # more than is free, less than free + pooled
+    assert left < want < left + held - 100 * MB
+    try:
+        ix = pm.Index.create(names, want // 512, layout=2)        # succeeds only because the pools were emptied
+        assert ix.info.device_bytes >= want - 512
+        ix.free()
+        # and a request that cannot fit either way still fails with the out-of-memory code, cleanly
+        with pytest.raises(pm.PMError) as e:
+            pm.Index.create(names, (4096 * MB) // 512, layout=2)
+        assert e.value.code == -3                                 # PM_ENOMEM
+    finally:
+        filler.free()
+        for q in sets:
+            q.free()
+    assert pm.device_info()["hbm_free"] > free_before

@@ -77,7 +77,8 @@ LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_ste
              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_narrow", "cpu_baseline", "gpu_over_cpu",
              "participants", "pm_kernels_blob", "hits", "legs_file")
 _ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "batches_per_launch",
-                  "avg_launch_ms", "algorithmic_bytes_per_launch", "hbm_GBps_from_traffic", "wire_frac_of_peak")
+                  "avg_launch_ms", "algorithmic_bytes_per_launch", "hbm_GBps_from_traffic", "wire_frac_of_peak", "traffic_source",
+                  "traffic_committed")
 _CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "partition", "runs", "sample_GB", "algorithmic_GBps", "timed_while")
 _CONFIG_KEYS = ("workload", "batches", "queries", "query_len", "k", "num_hashes", "threshold", "nb_best_hits", "rows_divisor",
                 "sharding", "scan_mode", "pipeline_depth")
@@ -115,6 +116,8 @@ def compact_line(full, legs_file=None):
         r = pick(full.get(k), _ROOFLINE_KEYS)
         if r is not None and r.get("traffic") is None and (full.get(k) or {}).get("traffic_note"):
             r["traffic_note"] = _clip(full[k]["traffic_note"], 200)
+        if r is not None and r.get("traffic_source"):
+            r["traffic_source"] = _clip(r["traffic_source"], 200)
         line[k] = r
     cb = pick(full.get("cpu_baseline"), _CPU_KEYS)
     if cb is not None:
@@ -159,6 +162,106 @@ def emit(full, legs_path, log=None):
     sys.stdout.write(text + "\n")
     sys.stdout.flush()
     return text
+
+
+# ---- HBM traffic of the scan kernels, measured in THIS run ------------------------------------------------------------
+# `roofline.traffic` used to be a constant committed under profiles/ (keyed to the kernel's git blob).  With one GPU the
+# bench now collects it itself once its own GPU work is done and its matrices are freed: two `rocprofv3 --kernel-trace
+# --pmc` child runs (one counter group each, as MI355X_MICROARCH.md prescribes: TCC slots do not hold both) of ONE
+# untimed step of the same workload, bytes = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B + 1024 x WRITE_SIZE per
+# launch (request sizes counted, not assumed: FETCH_SIZE tallies a 128-byte request at 64 on gfx950).  Any failure --
+# no rocprofv3, a pass that times out -- falls back to the committed table and says so.
+PMC_PASSES = (("rdreq", ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")),
+              ("write", ("WRITE_SIZE",)))
+
+
+def scan_kernel_name(raw):
+    """rocprofv3's `void pm::k_scan<32, 7, true, false>(pm::ScanArgs)` -> the name pm_launch_t / bench.py use"""
+    import re
+    m = re.search(r"k_scan<(\d+), (\d+), (true|false), (true|false)>", raw)
+    if not m:
+        return None
+    g, p_, nh1, wq = m.groups()
+    return f"k_scan<G={'mixed' if g == '0' else g},P={p_},{'NH1' if nh1 == 'true' else 'NHn'}{',WQ' if wq == 'true' else ''}>"
+
+
+def pmc_bytes_per_launch(counter_csvs):
+    """{kernel: {"hbm_bytes_per_launch", "read_requests", "write_bytes", "launches"}} from rocprofv3 counter_collection CSVs"""
+    import csv
+    acc = {}                                             # kernel -> counter -> [dispatches, sum]
+    for path in counter_csvs:
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                name = scan_kernel_name(row["Kernel_Name"])
+                if name:
+                    e = acc.setdefault(name, {}).setdefault(row["Counter_Name"], [0, 0.0])
+                    e[0] += 1; e[1] += float(row["Counter_Value"])
+    out = {}
+    for name, c in acc.items():
+        if "TCC_EA0_RDREQ_128B_sum" not in c or "WRITE_SIZE" not in c:
+            continue
+        mean = {k: v[1] / v[0] for k, v in c.items()}
+        rd = 128 * mean["TCC_EA0_RDREQ_128B_sum"] + 64 * mean.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 32 * mean.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        wr = 1024 * mean["WRITE_SIZE"]
+        out[name] = {"hbm_bytes_per_launch": int(rd + wr), "write_bytes": int(wr), "launches": c["TCC_EA0_RDREQ_128B_sum"][0],
+                     "read_requests": {k: int(mean.get(k, 0)) for k in PMC_PASSES[0][1]}}
+    return out
+
+
+def under_a_profiler():
+    return any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_pmc_traffic(workload_argv, budget_s, log):
+    """(per-kernel table or None, why-not or None, seconds): the PMC passes of one untimed step, as child processes"""
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    t0 = time.time()
+    exe = shutil.which("rocprofv3") or next((p_ for p_ in ("/opt/rocm/bin/rocprofv3",) if os.path.exists(p_)), None)
+    if not exe:
+        return None, "rocprofv3 is not installed on this host", 0.0
+    if under_a_profiler():
+        return None, "this run is itself being profiled", 0.0
+    work = tempfile.mkdtemp(prefix="pm_bench_pmc_", dir="/tmp")
+    csvs = []
+    try:
+        for tag, counters in PMC_PASSES:
+            left = budget_s - (time.time() - t0)
+            if left < 20:
+                return None, f"time budget of {budget_s:.0f} s used up before the {tag} pass", time.time() - t0
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(work, tag), "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                   "--only-headline", "--no-pipeline", "--no-live-pmc", "--legs-out", ""] + workload_argv
+            env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)          # the session this call started, nothing else
+                except OSError:
+                    pass
+                p.communicate()
+                return None, f"the {tag} pass did not finish within {left:.0f} s", time.time() - t0
+            if p.returncode != 0:
+                return None, f"the {tag} pass exited with status {p.returncode}: {err.decode(errors='replace')[-160:]!r}", time.time() - t0
+            found = glob.glob(os.path.join(work, tag, "**", "*counter_collection.csv"), recursive=True)
+            if not found:
+                return None, f"the {tag} pass wrote no counter_collection.csv", time.time() - t0
+            csvs += found
+        table = pmc_bytes_per_launch(csvs)
+        if not table:
+            return None, "no k_scan dispatch in the counter files", time.time() - t0
+        return table, None, time.time() - t0
+    except Exception as e:                                   # noqa: BLE001 -- an optional measurement never costs the line
+        return None, f"{e!r}", time.time() - t0
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def cpu_baseline(shapes, fasta_seqs, qlen, threshold, target_s, sample_gb, log):
@@ -281,6 +384,10 @@ def main():
     ap.add_argument("--legs-out", default="bench_legs.json",
                     help="side file for the WHOLE record (the stdout line + every auxiliary leg: threshold_bound, unique_rows, "
                          "argannot, clustered, l31, full_shard, full_collection, per-launch / per-rank detail); '' = none")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect the scan kernels' HBM traffic with rocprofv3 --pmc child runs at the end of a 1-GPU run "
+                         "(`roofline.traffic` then comes from the committed profiles/pmc_traffic.json, if that matches the kernel source)")
+    ap.add_argument("--live-pmc-budget-s", type=float, default=240.0, help="wall-clock cap of those child runs, both passes together")
     ap.add_argument("--whole-record", action="store_true",
                     help="developer tooling (tools/*.sh): print the WHOLE record as the stdout line instead of the compact one; "
                          "never what the driver runs -- the default line is capped at LINE_MAX_BYTES")
@@ -1058,6 +1165,37 @@ def main():
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
+    # ---- HBM traffic of the headline's scan kernels, from PMC passes of THIS run (one GPU; see live_pmc_traffic).  The
+    # GPU work of this process is over: its matrices, query sets and pooled buffers are released first, the children need the room
+    if ok and rank == 0 and world == 1 and not multi and full and not args.no_live_pmc and head == "fetch_all_rows":
+        for ix in indexes:
+            ix.free()
+        indexes = []
+        q.free()
+        pm.set_option("release_pools", 1)
+        wl = ["--workload", args.workload, "--queries", str(args.queries), "--qlen", str(args.qlen), "--threshold", str(args.threshold),
+              "--nb-best-hits", str(args.nb_best_hits), "--rows-divisor", str(args.rows_divisor), "--layout", str(args.layout)]
+        table, why, took = live_pmc_traffic(wl, args.live_pmc_budget_s, log)
+        log(f"[bench] live PMC passes: {'ok' if table else 'failed (' + str(why) + ')'} in {took:.1f}s")
+        out["live_pmc"] = {"seconds": round(took, 1), "kernels": table, "error": why,
+                           "how": "rocprofv3 --kernel-trace --pmc, one counter group per child run of `bench.py --steps 1 --warmup 0 "
+                                  "--only-headline --no-pipeline` on the same workload; bytes = 128 x TCC_EA0_RDREQ_128B_sum + 64 x _64B_sum "
+                                  "+ 32 x _32B_sum + 1024 x WRITE_SIZE per launch"}
+        for key in ("roofline", "roofline_narrow"):
+            r = out.get(key)
+            if not r:
+                continue
+            if table and r["kernel"] in table:
+                if r.get("traffic") is not None:
+                    r["traffic_committed"] = r["traffic"]                     # profiles/pmc_traffic.json, same kernel source: for comparison
+                r["traffic"] = table[r["kernel"]]["hbm_bytes_per_launch"]
+                r["hbm_GBps_from_traffic"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+                r["traffic_source"] = f"live: rocprofv3 --pmc passes run by this bench.py invocation ({took:.0f} s, {table[r['kernel']]['launches']} launch)"
+                r.pop("traffic_note", None)
+            elif r.get("traffic") is not None:
+                r["traffic_source"] = f"profiles/pmc_traffic.json (committed, same pm_kernels.hip blob); live pass: {why}"
+            else:
+                r["traffic_note"] = _clip(f"live pass: {why}; " + (r.get("traffic_note") or ""), 300)
     # the CPU path is timed in the same run at every N (north_star): rank 0 runs it on the host's cores while the other ranks
     # sleep on a key of the rendezvous store (a socket wait: no GPU work queued, no core spinning beside the CPU threads)
     if ok and not args.no_cpu_baseline:

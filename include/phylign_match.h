@@ -137,6 +137,9 @@ void pm_free(void* p);                    /* frees buffers documented as caller-
  * "release_query_pool" (any value; an action): the device buffers of query sets that gave their HBM copies back
  * (pm_queries_release_device) wait in a small pool for the next set -- freeing them on the spot would wait for every
  * search queued behind -- and this call really frees them (it waits for the device: call it between jobs).
+ * "release_pools" (any value; an action): the same for every idle device buffer the library keeps -- the query-set pool
+ * and the hit buffers of finished searches.  (The library does this by itself before it reports PM_ENOMEM for a
+ * signature matrix, a query set or a hit buffer.)
  * "cobs_threshold_rule" (default 0) / "cobs_tie_order" (default 0): the two rules of `cobs query` that no file of the
  * reference pins -- how -t becomes a minimum score: 0 = ceil(t x k-mers), 1 = floor, 2 = round half up; how documents of
  * equal score are listed: 0 = ascending document index, 1 = descending.  The defaults are upstream's as recalled

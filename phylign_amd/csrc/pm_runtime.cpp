@@ -217,6 +217,10 @@ extern "C" int pm_set_option(const char* name, int64_t value) try {
         if (g_ctx.ready) { bind_thread_quiet(); release_query_pool(); }
         return PM_OK;
     }
+    if (strcmp(name, "release_pools") == 0) {
+        if (g_ctx.ready) { bind_thread_quiet(); release_query_pool(); release_hit_pool(); }
+        return PM_OK;
+    }
     if (strcmp(name, "cobs_tie_order") == 0) {
         if (value < 0 || value > 1) return fail(PM_EINVAL, "cobs_tie_order takes 0 (equal scores by ascending document) or 1 (descending)");
         if ((uint32_t)value != g_tie_desc && g_live_results.load() > 0)

@@ -130,3 +130,39 @@ def test_bench_summary_reads_line_and_side_file(tmp_path):
     b = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_summary.py"), str(line_file)], capture_output=True, text=True)
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     assert "argannot x8" in a.stdout and a.stdout == b.stdout           # the line names its side file: same figures
+
+
+def test_live_pmc_parser_on_recorded_counter_files():
+    """bench.pmc_bytes_per_launch (the parser of the live PMC passes) on counter files recorded on an MI355X
+    (tests/golden/pmc: round 4, threshold-bound scan, two dispatches per kernel): per launch, bytes = 128 x RDREQ_128B +
+    64 x RDREQ_64B + 32 x RDREQ_32B + 1024 x WRITE_SIZE, the figures of profiles/r04/pmc_bench_n1_bound.txt"""
+    bench = _bench()
+    gold = os.path.join(ROOT, "tests", "golden", "pmc")
+    t = bench.pmc_bytes_per_launch([os.path.join(gold, "r04_bound_rdreq_counter_collection.csv"),
+                                    os.path.join(gold, "r04_bound_write_counter_collection.csv")])
+    assert set(t) == {"k_scan<G=32,P=7,NH1>", "k_scan<G=mixed,P=7,NH1>"}                 # k_hash_terms rows are not scan kernels
+    wide, narrow = t["k_scan<G=32,P=7,NH1>"], t["k_scan<G=mixed,P=7,NH1>"]
+    assert wide["launches"] == narrow["launches"] == 2
+    assert abs(wide["hbm_bytes_per_launch"] - (128 * 817172590.0 + 64 * 47586.5 + 1024 * 23952.4)) < 1024
+    assert abs(narrow["hbm_bytes_per_launch"] - (128 * 247918092.0 + 64 * 11205.5 + 1024 * 4419.6)) < 1024
+    assert wide["read_requests"]["TCC_EA0_RDREQ_32B_sum"] == 0 and wide["write_bytes"] == int(1024 * (511.0625 + 47393.78125) / 2)
+    # one pass missing (no WRITE_SIZE file): no figure rather than a partial one
+    assert bench.pmc_bytes_per_launch([os.path.join(gold, "r04_bound_rdreq_counter_collection.csv")]) == {}
+    assert bench.scan_kernel_name("void pm::k_scan<0, 13, true, true>(pm::ScanArgs)") == "k_scan<G=mixed,P=13,NH1,WQ>"
+    assert bench.scan_kernel_name("void pm::k_scan<64, 10, false, false>(pm::ScanArgs)") == "k_scan<G=64,P=10,NHn>"
+    assert bench.scan_kernel_name("pm::k_permute_runs(...)") is None
+
+
+def test_live_pmc_is_skipped_where_it_cannot_run(monkeypatch):
+    bench = _bench()
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+    assert bench.under_a_profiler()
+    monkeypatch.delenv("ROCPROFILER_SOMETHING")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.under_a_profiler()
+    monkeypatch.delenv("LD_PRELOAD")
+    if not bench.under_a_profiler():
+        import shutil
+        if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+            table, why, took = bench.live_pmc_traffic([], 60.0, print)
+            assert table is None and "not installed" in why

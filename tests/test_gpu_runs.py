@@ -230,14 +230,21 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     """the N>1 bench path (static sharding + packed gather, two ranks sharing the GPU over gloo)
     returns exactly the records of the single-rank run"""
     env = dict(os.environ, PYTHONPATH=ROOT)
-    common = ["--steps", "2", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline"]
+    common = ["--steps", "2", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline", "--no-live-pmc"]
     one = tmp_path / "one.npy"
     legs = tmp_path / "legs_one.json"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(one), "--legs-out", str(legs)],
-                       capture_output=True, env=env)
+    # (this first run keeps the live PMC passes: `roofline.traffic` is measured by rocprofv3 child runs of the same workload)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [a_ for a_ in common if a_ != "--no-live-pmc"] +
+                       ["--dump-hits", str(one), "--legs-out", str(legs)], capture_output=True, env=env)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     # the driver-facing line: small strict JSON with the contract's keys; every auxiliary leg is in the side file
     line, full = bench_record(r.stdout, legs)
+    lp = full["live_pmc"]
+    assert lp["error"] is None and lp["kernels"], lp
+    for key in ("roofline", "roofline_narrow"):
+        rf = line[key]
+        assert rf["traffic_source"].startswith("live: rocprofv3 --pmc") and rf["traffic"] == lp["kernels"][rf["kernel"]]["hbm_bytes_per_launch"] > 0
+        assert lp["kernels"][rf["kernel"]]["launches"] == 1 and abs(rf["hbm_GBps_from_traffic"] - rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * rf["hbm_GBps_from_traffic"]
     assert full["threshold_bound"]["hits_identical_to_headline"] and full["clustered"]["hits_identical"]
     assert line["roofline"]["frac"] < 1.0 and full["threshold_bound"]["roofline"]["frac"] < 1.0
     assert full["clustered"]["fetch_all_rows"]["hits"] > 20 * line["hits"]
@@ -485,7 +492,7 @@ def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
     the gathered records equal the one-rank run's, and so do those of the 305-batch full_collection leg"""
     env = dict(os.environ, PYTHONPATH=ROOT)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    common = ["--steps", "2", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline"]
+    common = ["--steps", "2", "--warmup", "1", "--rows-divisor", "400", "--queries", "3000", "--no-cpu-baseline", "--no-live-pmc"]
     one = tmp_path / "one.npy"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--dump-hits", str(one), "--only-headline"],
                        capture_output=True, env=env, cwd=tmp_path)

@@ -3,7 +3,7 @@
 # (the length mix of data/ARGannot_r3.fa, x1 and x8).  GPU box: bash tools/ab_qmap_sort.sh > gpurun_out/r05/ab_qmap_sort.txt
 for rep in 1 2; do
 for s in 0 1; do
-  PM_QMAP_SORT=$s python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --whole-record --no-full-shard --no-clustered --no-l31 --no-unique-rows 2>/dev/null | python3 -c "
+  PM_QMAP_SORT=$s python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-pmc --whole-record --no-full-shard --no-clustered --no-l31 --no-unique-rows 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 for x in ('x1','x8'):

@@ -6,7 +6,7 @@
 for rep in 1 2; do
 for maxp in 13 7 0; do
   PM_EXTRA_FLAGS="-DPM_SCAN_SHARE_MAX_P=$maxp" python3 phylign_amd/build.py > /dev/null 2>&1 || { echo "build failed: $maxp"; continue; }
-  python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --whole-record --no-full-shard --no-clustered --no-l31 --no-unique-rows 2>/dev/null | python3 -c "
+  python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-pmc --whole-record --no-full-shard --no-clustered --no-l31 --no-unique-rows 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 tag='SHARE_MAX_P=%s' % sys.argv[1]

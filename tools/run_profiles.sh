@@ -8,10 +8,10 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/fetch_all -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --whole-record --only-headline > $out/bench_fetch_all.json 2> $out/bench_fetch_all.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bound -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --whole-record --only-headline --headline threshold_bound > $out/bench_bound.json 2> $out/bench_bound.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/fetch_all -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-pmc --whole-record --only-headline > $out/bench_fetch_all.json 2> $out/bench_fetch_all.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bound -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-pmc --whole-record --only-headline --headline threshold_bound > $out/bench_bound.json 2> $out/bench_bound.log
 # the gene-length leg (the length mix of data/ARGannot_r3.fa): the 10- and 13-plane instantiations beside the headline's
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/argannot -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --whole-record --no-clustered --no-l31 --no-full-shard --no-unique-rows > $out/bench_argannot.json 2> $out/bench_argannot.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/argannot -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-pmc --whole-record --no-clustered --no-l31 --no-full-shard --no-unique-rows > $out/bench_argannot.json 2> $out/bench_argannot.log
 bash tools/run_pmc.sh ${tag}
 PMC_BENCH_FLAGS="--headline threshold_bound" bash tools/run_pmc.sh ${tag}_bound
 python3 tools/pmc_summary.py gpurun_out/pmc_${tag}/fetch gpurun_out/pmc_${tag}/rdreq gpurun_out/pmc_${tag}/hit gpurun_out/pmc_${tag}/write > $out/pmc_fetch_all.txt

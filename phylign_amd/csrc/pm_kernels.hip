@@ -256,6 +256,12 @@ __device__ __forceinline__ u32x4 ld_row(const uint8_t* p) {
 #ifndef PM_SCAN_SHARE_MAX_P
 #define PM_SCAN_SHARE_MAX_P 13       // widest counter class that shares (7: round 5's setting)
 #endif
+#ifndef PM_SCAN_PREFETCH_HASH
+#define PM_SCAN_PREFETCH_HASH 0      // 1: sharing instantiations load their hash of step s + 1 during step s (measured: no gain)
+#endif
+#ifndef PM_SCAN_PREFETCH_MAX_P
+#define PM_SCAN_PREFETCH_MAX_P 13
+#endif
 #ifndef PM_SCAN_MIN_WAVES
 #define PM_SCAN_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for
 #endif
@@ -356,6 +362,33 @@ __global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
     const uint32_t seg = (trips + nsplit - 1u) / nsplit;
     const uint32_t it_begin = WQ ? blockIdx.z * seg : 0u;
     const uint32_t it_end = WQ ? (it_begin + seg < trips ? it_begin + seg : trips) : trips;
+    // The lanes of a group all need the same TS rows.  With 8+ lanes per group and one hash function each
+    // lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett reduction instead of TS
+    // of each) and the group shares the ROW INDICES by ds_bpermute; every lane takes part in the exchange,
+    // alive or not (a disabled source lane would deliver 0).  A row index fits 32 bits here: G >= 8 means
+    // a stride of at least 128 bytes, and rows x stride is resident in HBM (pm_index.cpp checks it against
+    // the device's memory), so rows < 309 GB / 128 B < 2^32.  One exchanged register per k-mer (the byte
+    // offset is one v_mad_u64_u32 per lane): 8 registers instead of the 16 that round 5's exchange of 64-bit
+    // offsets took, which is what lets the 10- and 13-plane classes (40 / 52 plane registers) share as well.
+    constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8 && P <= PM_SCAN_SHARE_MAX_P;
+    // Build option PM_SCAN_PREFETCH_HASH (off): my hash of a step is loaded ONE STEP AHEAD -- issued behind the row
+    // gathers of the current step, so that a step's dependent chain is gather -> count instead of hash load ->
+    // reduce -> gather -> count.  The block index is clamped to the query's own blocks: the load is unconditional
+    // and always in bounds, and a value fetched for a k-mer that does not exist is never used (lane i of the group
+    // reads rows[i] only when k-mer i of the step exists).  Measured (profiles/r06/ab_prefetch_hash.txt): within
+    // +-0.3 % on the 7- and 10-plane classes, +1.2 % on the 13-plane class at the price of 1-5 spilled VGPRs and
+    // -6 % on its wide-query form: with four waves per SIMD the other waves' gathers already cover the hash load,
+    // and the launch is bound by the rate of 128-byte lines the memory system delivers.  Records are identical
+    // either way (the parity suite ran on both builds).
+    constexpr bool PREFETCH = SHARE && PM_SCAN_PREFETCH_HASH && P <= PM_SCAN_PREFETCH_MAX_P;
+    const uint32_t i_mine = c & (uint32_t)(TS - 1);
+    const uint32_t qblk = qv ? (nt + 7u) >> 3 : 0u;
+    auto my_hash_of_step = [&](uint32_t step) -> uint64_t {
+        const uint32_t blk = step / SPB;
+        return a.hashes[(pb + (blk < qblk ? blk : (qblk ? qblk - 1u : 0u))) * 8 + i_mine];       // [blk][hash 0][8]
+    };
+    uint64_t h_next = 0;
+    if constexpr (PREFETCH) h_next = my_hash_of_step(WQ ? it_begin * ngrp + sub : it_begin);
     for (uint32_t it = it_begin; it < it_end; ++it) {
         const uint32_t sidx = WQ ? it * ngrp + sub : it;          // my step of the query
         const uint32_t b = sidx / SPB, t0i = sidx * TS;           // block, first k-mer of this step
@@ -379,21 +412,11 @@ __global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
         u32x4 x[TS];
 #pragma unroll
         for (int i = 0; i < TS; ++i) x[i] = (u32x4)(0u);
-        // The lanes of a group all need the same TS rows.  With 8+ lanes per group and one hash function each
-        // lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett reduction instead of TS
-        // of each) and the group shares the ROW INDICES by ds_bpermute; every lane takes part in the exchange,
-        // alive or not (a disabled source lane would deliver 0).  A row index fits 32 bits here: G >= 8 means
-        // a stride of at least 128 bytes, and rows x stride is resident in HBM (pm_index.cpp checks it against
-        // the device's memory), so rows < 309 GB / 128 B < 2^32.  One exchanged register per k-mer, consumed by
-        // (the byte offset is one v_mad_u64_u32 per lane): 8 registers instead of the 16 that round 5's exchange
-        // of 64-bit offsets took, which is what lets the 10- and 13-plane classes (40 / 52 plane registers)
-        // share as well.
-        constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8 && P <= PM_SCAN_SHARE_MAX_P;
         uint32_t my_row = 0;
-        if constexpr (SHARE) {
-            const uint32_t i_mine = c & (uint32_t)(TS - 1);
-            if (qv && t0i + i_mine < nt)
-                my_row = (uint32_t)mod_sig(a.hashes[(pb + b) * 8 + i_mine], S, bm);      // [blk][hash 0][8]
+        if constexpr (PREFETCH) {
+            my_row = (uint32_t)mod_sig(h_next, S, bm);
+        } else if constexpr (SHARE) {
+            if (qv && t0i + i_mine < nt) my_row = (uint32_t)mod_sig(a.hashes[(pb + b) * 8 + i_mine], S, bm);
         }
         const bool go = active && t0i < nt && line_alive;
         const uint32_t left = go ? nt - t0i : 0u;         // valid k-mers of this step for this lane (0: no gather)
@@ -429,6 +452,7 @@ __global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
                 for (int i = 0; i < TS; ++i) x[i] = (j == 0) ? v[i] : (x[i] & v[i]);
             }
         }
+        if constexpr (PREFETCH) h_next = my_hash_of_step(WQ ? (it + 1u) * ngrp + sub : it + 1u);   // lands under the gathers
         // TS one-bit inputs -> low planes by carry-save adders + one carry rippling upwards
         u32x4 t0, t1, f0;
         PM_CSA(pl[0], t0, pl[0], x[0], x[1]);

@@ -236,8 +236,13 @@ def live_pmc_traffic(workload_argv, budget_s, log):
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                    "--only-headline", "--no-pipeline", "--no-live-pmc", "--legs-out", ""] + workload_argv
             env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-                env.pop(k, None)
+            # the child is a plain one-process run: nothing of this rank's launcher / process group may reach it
+            # (PHYLIGN_LAUNCHER_PID would make it end itself: its parent is the profiler, not the launcher)
+            for k in list(env):
+                if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                         "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "PHYLIGN_LAUNCHER_PID", "BENCH_FORCE_DIST", "BENCH_FORCE_GATHER",
+                         "BENCH_DIST_BACKEND", "BENCH_FULL_MIN_WORLD") or k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC")):
+                    env.pop(k)
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
             try:
                 _, err = p.communicate(timeout=left)
@@ -1165,55 +1170,65 @@ def main():
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
-    # ---- HBM traffic of the headline's scan kernels, from PMC passes of THIS run (one GPU; see live_pmc_traffic).  The
-    # GPU work of this process is over: its matrices, query sets and pooled buffers are released first, the children need the room
-    if ok and rank == 0 and world == 1 and not multi and full and not args.no_live_pmc and head == "fetch_all_rows":
-        for ix in indexes:
-            ix.free()
-        indexes = []
-        q.free()
-        pm.set_option("release_pools", 1)
-        wl = ["--workload", args.workload, "--queries", str(args.queries), "--qlen", str(args.qlen), "--threshold", str(args.threshold),
-              "--nb-best-hits", str(args.nb_best_hits), "--rows-divisor", str(args.rows_divisor), "--layout", str(args.layout)]
-        table, why, took = live_pmc_traffic(wl, args.live_pmc_budget_s, log)
-        log(f"[bench] live PMC passes: {'ok' if table else 'failed (' + str(why) + ')'} in {took:.1f}s")
-        out["live_pmc"] = {"seconds": round(took, 1), "kernels": table, "error": why,
-                           "how": "rocprofv3 --kernel-trace --pmc, one counter group per child run of `bench.py --steps 1 --warmup 0 "
-                                  "--only-headline --no-pipeline` on the same workload; bytes = 128 x TCC_EA0_RDREQ_128B_sum + 64 x _64B_sum "
-                                  "+ 32 x _32B_sum + 1024 x WRITE_SIZE per launch"}
-        for key in ("roofline", "roofline_narrow"):
-            r = out.get(key)
-            if not r:
-                continue
-            if table and r["kernel"] in table:
-                if r.get("traffic") is not None:
-                    r["traffic_committed"] = r["traffic"]                     # profiles/pmc_traffic.json, same kernel source: for comparison
-                r["traffic"] = table[r["kernel"]]["hbm_bytes_per_launch"]
-                r["hbm_GBps_from_traffic"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
-                r["traffic_source"] = f"live: rocprofv3 --pmc passes run by this bench.py invocation ({took:.0f} s, {table[r['kernel']]['launches']} launch)"
-                r.pop("traffic_note", None)
-            elif r.get("traffic") is not None:
-                r["traffic_source"] = f"profiles/pmc_traffic.json (committed, same pm_kernels.hip blob); live pass: {why}"
-            else:
-                r["traffic_note"] = _clip(f"live pass: {why}; " + (r.get("traffic_note") or ""), 300)
-    # the CPU path is timed in the same run at every N (north_star): rank 0 runs it on the host's cores while the other ranks
-    # sleep on a key of the rendezvous store (a socket wait: no GPU work queued, no core spinning beside the CPU threads)
-    if ok and not args.no_cpu_baseline:
+    # ---- after the timed legs rank 0 works alone while the other ranks sleep on a key of the rendezvous store (a socket wait: no
+    # GPU work queued, no core spinning beside the CPU threads):
+    # (1) HBM traffic of the headline's scan kernels from PMC passes of THIS run (see live_pmc_traffic).  The GPU work of this
+    #     process is over: its matrices, query sets and pooled buffers are released first, the children need the room.  With
+    #     N > 1 the children hold the shard rank 0 had (--emulate-world N --emulate-rank 0) on rank 0's GPU: the line's
+    #     `roofline` is rank 0's launch, and so is its `traffic`.
+    # (2) the CPU path, timed in the same run at every N (north_star) on the host's cores.
+    want_pmc = full and not args.no_live_pmc and head == "fetch_all_rows"
+    want_cpu = not args.no_cpu_baseline
+    if ok and rank == 0 and not want_cpu:
+        out["cpu_baseline"] = None
+    if ok and (want_pmc or want_cpu):
         if rank == 0:
             try:
-                out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,
-                                                   args.cpu_target_s, args.cpu_sample_gb, log)
-                out["cpu_baseline"]["timed_while"] = ("the only process on the host" if world == 1 else
-                                                      f"the other {world - 1} ranks slept on a rendezvous-store key, GPUs idle")
-                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                if want_pmc:
+                    for ix in indexes:
+                        ix.free()
+                    indexes = []
+                    q.free()
+                    pm.set_option("release_pools", 1)
+                    wl = ["--workload", args.workload, "--queries", str(args.queries), "--qlen", str(args.qlen), "--threshold", str(args.threshold),
+                          "--nb-best-hits", str(args.nb_best_hits), "--rows-divisor", str(args.rows_divisor), "--layout", str(args.layout)]
+                    if world > 1:
+                        wl += ["--emulate-world", str(world), "--emulate-rank", "0"] + (["--replicas"] if args.replicas else [])
+                    table, why, took = live_pmc_traffic(wl, args.live_pmc_budget_s, log)
+                    log(f"[bench] live PMC passes: {'ok' if table else 'failed (' + str(why) + ')'} in {took:.1f}s")
+                    out["live_pmc"] = {"seconds": round(took, 1), "kernels": table, "error": why,
+                                       "how": "rocprofv3 --kernel-trace --pmc, one counter group per child run of `bench.py --steps 1 --warmup 0 "
+                                              "--only-headline --no-pipeline` on the same workload" +
+                                              (f" and rank 0's shard of the {world}-way split (--emulate-world {world} --emulate-rank 0)" if world > 1 else "") +
+                                              "; bytes = 128 x TCC_EA0_RDREQ_128B_sum + 64 x _64B_sum + 32 x _32B_sum + 1024 x WRITE_SIZE per launch"}
+                    for key in ("roofline", "roofline_narrow"):
+                        r = out.get(key)
+                        if not r:
+                            continue
+                        if table and r["kernel"] in table:
+                            if r.get("traffic") is not None:
+                                r["traffic_committed"] = r["traffic"]             # profiles/pmc_traffic.json, same kernel source: for comparison
+                            r["traffic"] = table[r["kernel"]]["hbm_bytes_per_launch"]
+                            r["hbm_GBps_from_traffic"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+                            r["traffic_source"] = (f"live: rocprofv3 --pmc passes run by this bench.py invocation ({took:.0f} s, "
+                                                   f"{table[r['kernel']]['launches']} launch" + (f", rank 0's shard of {world}" if world > 1 else "") + ")")
+                            r.pop("traffic_note", None)
+                        elif r.get("traffic") is not None:
+                            r["traffic_source"] = f"profiles/pmc_traffic.json (committed, same pm_kernels.hip blob); live pass: {why}"
+                        else:
+                            r["traffic_note"] = _clip(f"live pass: {why}; " + (r.get("traffic_note") or ""), 300)
+                if want_cpu:
+                    out["cpu_baseline"] = cpu_baseline(shapes, seqs, args.qlen, args.threshold,
+                                                       args.cpu_target_s, args.cpu_sample_gb, log)
+                    out["cpu_baseline"]["timed_while"] = ("the only process on the host" if world == 1 else
+                                                          f"the other {world - 1} ranks slept on a rendezvous-store key, GPUs idle")
+                    out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             finally:
                 if world > 1:
                     rendezvous_store().set("bench/cpu_baseline_done", "1")
         elif world > 1:
             from datetime import timedelta
             rendezvous_store().wait(["bench/cpu_baseline_done"], timedelta(seconds=1500))
-    elif rank == 0:
-        out["cpu_baseline"] = None
     if ok and rank == 0:
         if args.whole_record:
             flush_c_stdio()

@@ -207,7 +207,7 @@ def test_names_without_separator_are_cut_on_the_host(pm, oracle):
     assert pm.format_hits(ix, q, got, nb_best_hits=-1) == oracle.query_file(index, fasta, 0.7)
 
 
-def _check_multi_rank_line(line, full, n):
+def _check_multi_rank_line(line, full, n, live_pmc=False):
     """what makes an N > 1 bench line count as measured: cpu_baseline and roofline present in the LINE, ranks
     counted; the auxiliary legs sit in the side file, left out WITH the reason where they do not apply"""
     cb = line["cpu_baseline"]
@@ -215,7 +215,15 @@ def _check_multi_rank_line(line, full, n):
     assert line["gpu_over_cpu"] > 0
     rf = line["roofline"]
     assert rf and rf["bound"] == "hbm" and 0 < rf["frac"] < 1.0 and rf["peak"] == 8000.0 and rf["achieved"] > 0
-    assert rf["traffic"] is None and "1-rank launch" in rf["traffic_note"]
+    lp = full.get("live_pmc")
+    if live_pmc and lp and lp["error"] is None:
+        # rank 0 measured its own launch: PMC child runs on the shard it held, the other ranks asleep
+        assert rf["traffic"] == lp["kernels"][rf["kernel"]]["hbm_bytes_per_launch"] > 0 and f"rank 0's shard of {n}" in rf["traffic_source"]
+        assert f"--emulate-world {n} --emulate-rank 0" in lp["how"]
+    elif live_pmc:
+        assert rf["traffic"] is None and "live pass" in rf["traffic_note"]
+    else:
+        assert rf["traffic"] is None and "1-rank launch" in rf["traffic_note"]
     assert line["n_gpus"] == n and line["participants"]["ranks"] == n
     assert "rccl_ranks" in line["participants"]          # null over gloo (these tests), N over RCCL
     ur = full["unique_rows"]
@@ -240,11 +248,20 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     # the driver-facing line: small strict JSON with the contract's keys; every auxiliary leg is in the side file
     line, full = bench_record(r.stdout, legs)
     lp = full["live_pmc"]
-    assert lp["error"] is None and lp["kernels"], lp
-    for key in ("roofline", "roofline_narrow"):
-        rf = line[key]
-        assert rf["traffic_source"].startswith("live: rocprofv3 --pmc") and rf["traffic"] == lp["kernels"][rf["kernel"]]["hbm_bytes_per_launch"] > 0
-        assert lp["kernels"][rf["kernel"]]["launches"] == 1 and abs(rf["hbm_GBps_from_traffic"] - rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * rf["hbm_GBps_from_traffic"]
+    if lp["error"] is None:
+        assert lp["kernels"], lp
+        for key in ("roofline", "roofline_narrow"):
+            rf = line[key]
+            assert rf["traffic_source"].startswith("live: rocprofv3 --pmc") and rf["traffic"] == lp["kernels"][rf["kernel"]]["hbm_bytes_per_launch"] > 0
+            assert lp["kernels"][rf["kernel"]]["launches"] == 1 and abs(rf["hbm_GBps_from_traffic"] - rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * rf["hbm_GBps_from_traffic"]
+    else:
+        # a box where the profiler cannot run (no rocprofv3, a run that is itself profiled): the line says so and falls
+        # back to the committed table or null -- an optional measurement never costs the line
+        import warnings
+        warnings.warn(f"live PMC passes did not run here: {lp['error']}")
+        for key in ("roofline", "roofline_narrow"):
+            rf = full[key]
+            assert lp["kernels"] is None and "live pass" in (rf.get("traffic_source") or rf.get("traffic_note") or "")
     assert full["threshold_bound"]["hits_identical_to_headline"] and full["clustered"]["hits_identical"]
     assert line["roofline"]["frac"] < 1.0 and full["threshold_bound"]["roofline"]["frac"] < 1.0
     assert full["clustered"]["fetch_all_rows"]["hits"] > 20 * line["hits"]
@@ -266,7 +283,7 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     env2 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
     # every N > 1 line is self-sufficient: the CPU path is timed in the same run (rank 0, the other rank sleeps on a store
     # key), `roofline` is there with `traffic` null AND the reason, the ranks are counted
-    small_cpu = [a_ for a_ in common if a_ != "--no-cpu-baseline"] + ["--cpu-target-s", "0.6", "--cpu-sample-gb", "0.2"]
+    small_cpu = [a_ for a_ in common if a_ not in ("--no-cpu-baseline", "--no-live-pmc")] + ["--cpu-target-s", "0.6", "--cpu-sample-gb", "0.2"]
     legs2 = tmp_path / "legs_two.json"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
@@ -278,7 +295,7 @@ def test_bench_two_ranks_equal_one_rank(pm, tmp_path):
     line2, full2 = bench_record(r.stdout, legs2)
     part = line2["participants"]
     assert part["ranks"] == 2 and len(part["rank_ms_per_step"]) == 2 and part["rank_devices"] == [0, 0]
-    _check_multi_rank_line(line2, full2, 2)
+    _check_multi_rank_line(line2, full2, 2, live_pmc=True)
     assert sum(part["rank_batches"]) == 64 and min(part["rank_batches"]) >= 1
     assert abs(max(part["rank_ms_per_step"]) - line2["ms_per_step"]) < 1e-3          # the job's step is the slowest rank's
     assert abs(max(full2["participants"]["rank_ms_per_step"]) - line2["ms_per_step"]) < 1e-9
@@ -501,14 +518,16 @@ def test_bench_plain_invocation_with_eight_ranks_equals_one_rank(pm, tmp_path):
     assert line1["n_gpus"] == 1 and line1["cpu_baseline"] is None
     eight, fullc, legs8 = tmp_path / "eight.npy", tmp_path / "fullc.npy", tmp_path / "legs_eight.json"
     env8 = dict(env, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_FULL_MIN_WORLD="8")
-    small_cpu = [a_ for a_ in common if a_ != "--no-cpu-baseline"] + ["--cpu-target-s", "0.6", "--cpu-sample-gb", "0.2"]
+    # (the self-launched ranks carry PHYLIGN_LAUNCHER_PID: rank 0's PMC children must not inherit it, or they end themselves)
+    small_cpu = [a_ for a_ in common if a_ not in ("--no-cpu-baseline", "--no-live-pmc")] + ["--cpu-target-s", "0.6", "--cpu-sample-gb", "0.2"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--replicas"] + small_cpu +
                        ["--dump-hits", str(eight), "--dump-full-hits", str(fullc), "--legs-out", str(legs8)], capture_output=True, env=env8)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     # ONE JSON line, from rank 0, the last thing on stdout, under the size cap with all 8 ranks AND the full_collection leg run
     line, full = bench_record(r.stdout, legs8)
     assert len(r.stdout.decode().rstrip("\n").splitlines()[-1]) < 6144
-    _check_multi_rank_line(line, full, 8)
+    _check_multi_rank_line(line, full, 8, live_pmc=True)
+    assert full["live_pmc"]["error"] is None or "rocprofv3" in full["live_pmc"]["error"], full["live_pmc"]
     part = line["participants"]
     assert line["n_gpus"] == 8 and part["ranks"] == 8 and len(part["rank_ms_per_step"]) == 8
     shared = full["config"]["batches_on_two_ranks"]

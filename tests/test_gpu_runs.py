@@ -623,18 +623,20 @@ def test_index_allocation_reclaims_the_librarys_idle_pools(pm):
         q.release_device()                                       # -> pooled, not freed
     free_pooled = pm.device_info()["hbm_free"]
     assert free_pooled - free_before < held // 4                 # the pool still holds (most of) it
-    filler = pm.Index.create(names, (free_pooled - 300 * MB) // 512, layout=2)
+    filler = pm.Index.create(names, (free_pooled - 1024 * MB) // 512, layout=2)      # leaves 1 GB: far from any allocation-granularity effect
     left = pm.device_info()["hbm_free"]
-    assert left < 400 * MB
-    want = 900 * MB                                              # more than is free, less than free + pooled
+    assert left < 1100 * MB
+    want = 1700 * MB                                             # more than is free, less than free + pooled
     assert left < want < left + held - 100 * MB
     try:
         ix = pm.Index.create(names, want // 512, layout=2)        # succeeds only because the pools were emptied
         assert ix.info.device_bytes >= want - 512
         ix.free()
         # and a request that cannot fit either way still fails with the out-of-memory code, cleanly
+        # (sized from what is free NOW: the reclaim above also returned the hit buffers earlier tests left in their pool)
+        too_much = pm.device_info()["hbm_free"] + 16384 * MB
         with pytest.raises(pm.PMError) as e:
-            pm.Index.create(names, (4096 * MB) // 512, layout=2)
+            pm.Index.create(names, too_much // 512, layout=2)
         assert e.value.code == -3                                 # PM_ENOMEM
     finally:
         filler.free()

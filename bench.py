@@ -212,7 +212,7 @@ def under_a_profiler():
     return any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def live_pmc_traffic(workload_argv, budget_s, log):
+def live_pmc_traffic(workload_argv, budget_s, log, min_pass_s=20.0):
     """(per-kernel table or None, why-not or None, seconds): the PMC passes of one untimed step, as child processes"""
     import glob
     import shutil
@@ -230,7 +230,7 @@ def live_pmc_traffic(workload_argv, budget_s, log):
     try:
         for tag, counters in PMC_PASSES:
             left = budget_s - (time.time() - t0)
-            if left < 20:
+            if left < min_pass_s:
                 return None, f"time budget of {budget_s:.0f} s used up before the {tag} pass", time.time() - t0
             cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(work, tag), "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",

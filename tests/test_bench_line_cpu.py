@@ -166,3 +166,78 @@ def test_live_pmc_is_skipped_where_it_cannot_run(monkeypatch):
         if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
             table, why, took = bench.live_pmc_traffic([], 60.0, print)
             assert table is None and "not installed" in why
+
+
+def _fake_rocprofv3(tmp_path, body):
+    d = tmp_path / "bin"
+    d.mkdir(exist_ok=True)
+    exe = d / "rocprofv3"
+    exe.write_text("#!/usr/bin/env bash\n" + body)
+    exe.chmod(0o755)
+    return str(d)
+
+
+def test_live_pmc_passes_with_a_stand_in_profiler(tmp_path, monkeypatch):
+    """bench.live_pmc_traffic end to end on CPU with a stand-in `rocprofv3` on PATH: two child runs (one counter group each),
+    the counter files they leave are parsed, the scratch directory is removed; a pass that exits non-zero, writes nothing or
+    overruns the time budget yields (None, reason) -- never an exception, never a partial figure -- and the process group the
+    call started is gone afterwards.  No launcher / process-group variable of the calling rank reaches the children."""
+    bench = _bench()
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_", "ROCTX")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    gold = os.path.join(ROOT, "tests", "golden", "pmc")
+    seen = tmp_path / "seen.txt"
+    # the stand-in: finds `-d DIR`, copies the recorded file of the counter group it was asked for, records argv + env
+    ok_body = f'''
+args=("$@"); dir=""
+for ((i=0; i<${{#args[@]}}; i++)); do [ "${{args[$i]}}" = "-d" ] && dir="${{args[$((i+1))]}}"; done
+mkdir -p "$dir/host/1"
+if printf '%s\\n' "$@" | grep -q WRITE_SIZE; then cp {gold}/r04_bound_write_counter_collection.csv "$dir/host/1/pmc_counter_collection.csv"
+else cp {gold}/r04_bound_rdreq_counter_collection.csv "$dir/host/1/pmc_counter_collection.csv"; fi
+echo "ARGV $*" >> {seen}; echo "ENV launcher=${{PHYLIGN_LAUNCHER_PID:-none}} rank=${{RANK:-none}} world=${{WORLD_SIZE:-none}} force=${{BENCH_FORCE_DIST:-none}} cwd=$PWD tmp=$TMPDIR" >> {seen}
+'''
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, ok_body) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("PHYLIGN_LAUNCHER_PID", "1")            # what a self-launched rank 0 carries
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("BENCH_FORCE_DIST", "1")
+    logged = []
+    table, why, took = bench.live_pmc_traffic(["--workload", "config3", "--emulate-world", "8", "--emulate-rank", "0"], 60.0, logged.append)
+    assert why is None and set(table) == {"k_scan<G=32,P=7,NH1>", "k_scan<G=mixed,P=7,NH1>"} and took < 30
+    assert abs(table["k_scan<G=32,P=7,NH1>"]["hbm_bytes_per_launch"] - (128 * 817172590.0 + 64 * 47586.5 + 1024 * 23952.4)) < 1024
+    text = seen.read_text()
+    assert text.count("ARGV") == 2 and text.count("--pmc TCC_EA0_RDREQ_sum") == 1 and text.count("--pmc WRITE_SIZE") == 1
+    assert "--kernel-trace" in text and "--sys-trace" not in text and "--hip-trace" not in text         # the combination gpurun allows
+    assert "--steps 1 --warmup 0 --no-cpu-baseline --only-headline --no-pipeline --no-live-pmc" in text and "--emulate-world 8 --emulate-rank 0" in text
+    assert text.count("ENV launcher=none rank=none world=none force=none cwd=/tmp tmp=/tmp") == 2
+    assert not [d for d in os.listdir("/tmp") if d.startswith("pm_bench_pmc_") and os.path.getmtime(os.path.join("/tmp", d)) > os.path.getmtime(str(seen)) - 60 and not os.listdir(os.path.join("/tmp", d))]
+    # failures: each a reason, not an exception
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, "echo boom >&2; exit 3\n") + os.pathsep + os.environ["PATH"])
+    table, why, _ = bench.live_pmc_traffic([], 60.0, logged.append)
+    assert table is None and "status 3" in why and "boom" in why
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, "exit 0\n") + os.pathsep + os.environ["PATH"])
+    table, why, _ = bench.live_pmc_traffic([], 60.0, logged.append)
+    assert table is None and "no counter_collection.csv" in why
+    pidfile = tmp_path / "grandchild.pid"
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, f"sleep 600 & echo $! > {pidfile}; wait\n") + os.pathsep + os.environ["PATH"])
+    import time
+    t0 = time.time()
+    table, why, took = bench.live_pmc_traffic([], 2.0, logged.append, min_pass_s=0.5)
+    assert table is None and "did not finish" in why and time.time() - t0 < 15
+    pid = int(pidfile.read_text())                                 # the stand-in's own child: ended with the session, by its exact id
+
+    def gone(pid_):
+        try:
+            return open(f"/proc/{pid_}/stat").read().rsplit(")", 1)[1].split()[0] == "Z"
+        except OSError:
+            return True
+    t0 = time.time()
+    while not gone(pid) and time.time() - t0 < 5:
+        time.sleep(0.05)
+    assert gone(pid)
+    table, why, _ = bench.live_pmc_traffic([], 1.0, logged.append)                                       # budget below one pass
+    assert table is None and "time budget" in why
+    # a run that is itself profiled never nests a profiler
+    monkeypatch.setenv("ROCPROFILER_REGISTER_SOMETHING", "1")
+    table, why, _ = bench.live_pmc_traffic([], 60.0, logged.append)
+    assert table is None and "being profiled" in why

@@ -108,6 +108,12 @@ static int finish_index_shape(pm_index* ix, const ParsedHeader& h, int layout, b
     uint64_t lanes = (std::min<uint64_t>(stride, 1024) + 15) / 16;
     ix->g = (int)pow2ceil(lanes);
     ix->slabs = (uint32_t)((stride + 1023) / 1024);
+    // k_scan's lane groups of 8+ lanes exchange 32-bit ROW INDICES (pm_kernels.hip, SHARE).  8+ lanes mean a stride of more
+    // than 64 bytes, so 2^32 rows would be a matrix of 275 GB+: check_matrix_size above already refused anything this GPU
+    // cannot hold.  Stated here as a check of its own so that a device with more memory fails loudly instead of wrapping.
+    if (ix->g >= 8 && h.sig > 0xFFFFFFFFull)
+        return fail(PM_ERANGE, "index has %llu rows of %llu bytes: the scan addresses at most 2^32 rows of this width",
+                    (unsigned long long)h.sig, (unsigned long long)stride);
     const auto t_m0 = std::chrono::steady_clock::now();
     hipError_t e = device_malloc_reclaim((void**)&ix->d_matrix, in.device_bytes);   // idle pooled buffers go first
     if (getenv("PM_LOAD_TRACE"))
@@ -486,6 +492,8 @@ static int load_from_reader(Reader& rd, uint64_t size_hint, int layout, bool hea
             part->g = (int)pow2ceil((std::min<uint64_t>(stride, 1024) + 15) / 16);
             part->slabs = (uint32_t)((stride + 1023) / 1024);
             rc = check_matrix_size(pc.sig[p], sa);
+            if (!rc && part->g >= 8 && pc.sig[p] > 0xFFFFFFFFull)      // (see finish_index_shape: 32-bit row indices in k_scan)
+                rc = fail(PM_ERANGE, "sub-index %u has %llu rows: the scan addresses at most 2^32 rows of this width", p, (unsigned long long)pc.sig[p]);
             hipError_t e = rc ? hipSuccess : device_malloc_reclaim((void**)&part->d_matrix, in.device_bytes);
             if (rc) {}
             else if (e != hipSuccess || !part->d_matrix) {

@@ -366,8 +366,9 @@ __global__ __launch_bounds__(256, (P <= 13 ? PM_SCAN_MIN_WAVES : (P <= 16 ? (WQ 
     // lane maps ONE k-mer (lane c takes k-mer c mod TS: one hash load, one Barrett reduction instead of TS
     // of each) and the group shares the ROW INDICES by ds_bpermute; every lane takes part in the exchange,
     // alive or not (a disabled source lane would deliver 0).  A row index fits 32 bits here: G >= 8 means
-    // a stride of at least 128 bytes, and rows x stride is resident in HBM (pm_index.cpp checks it against
-    // the device's memory), so rows < 309 GB / 128 B < 2^32.  One exchanged register per k-mer (the byte
+    // a stride of at least 80 bytes (128 in the aligned layout), and rows x stride is resident in HBM, so
+    // rows < 309 GB / 80 B < 2^32 (pm_index.cpp refuses 2^32 rows of such a width outright, whatever the
+    // device's memory).  One exchanged register per k-mer (the byte
     // offset is one v_mad_u64_u32 per lane): 8 registers instead of the 16 that round 5's exchange of 64-bit
     // offsets took, which is what lets the 10- and 13-plane classes (40 / 52 plane registers) share as well.
     constexpr bool SHARE = PM_SCAN_SHARE_ROWS && NH1 && G >= TS && TS == 8 && P <= PM_SCAN_SHARE_MAX_P;

@@ -3,7 +3,6 @@ line had grown to 28.6 KB; since round 6 the last stdout line is a small strict-
 cpu_baseline + who took part) and the auxiliary legs go to a side file.  These tests rebuild the line from RECORDED
 round-5 records (whole dicts, as bench.py assembled them on the GPU box) and from a synthetic worst case."""
 import copy
-import io
 import json
 import os
 import sys

@@ -15,15 +15,23 @@ batch index.  Workload (BASELINE.json configs[2], SURVEY.md 8d "config 3"): the
 synthetic 150-bp queries (120 31-mers each), threshold 0.7.  With N > 1 the same
 64 batches are sharded statically over the ranks (strong scaling).
 
+Output: the LAST stdout line is one small strict-JSON object (compact_line: the contract's
+keys + roofline + roofline_narrow + cpu_baseline + participants; < 6 KB by construction);
+the WHOLE record -- that line's content plus every auxiliary leg below -- is written to the
+side file --legs-out (default ./bench_legs.json).  roofline.traffic is measured in the run:
+after the timed legs rank 0 runs two `rocprofv3 --kernel-trace --pmc` child passes over one
+untimed step of its own launch (live_pmc_traffic); --no-live-pmc falls back to the table
+committed under profiles/.
+
 What is reported where:
   value / roofline     every signature row of every k-mer is gathered, like `cobs
                        query` does ("fetch_all_rows"): independent of the data, and
                        the algorithmic bytes are the bytes the kernel really moves.
-  threshold_bound      the product default: lines whose documents cannot reach the
+  threshold_bound      (side file) the product default: lines whose documents cannot reach the
                        threshold any more are not fetched (identical results).  Its
                        speed depends on the data, so it is a secondary figure, and
                        its roofline uses the bytes really gathered (counted in-kernel).
-  clustered            the same two modes after every query was given a HOME batch in
+  clustered            (side file) the same two modes after every query was given a HOME batch in
                        which about half of the documents match it at 0.6-1.0 of its
                        k-mers (what phylogenetic batches look like for reads of their
                        own species): many documents near the threshold, long hit lists.

@@ -1243,6 +1243,11 @@ def main():
             print(json.dumps(out, allow_nan=False), flush=True)
         else:
             emit(out, args.legs_out, log)
+        # the same headline on stderr, in words: whoever reads only the log tail still sees what the line said
+        rf_, cb_ = out.get("roofline") or {}, out.get("cpu_baseline") or {}
+        log(f"[bench] n_gpus {world}: {out['value']:.4g} k-mers/s, {out['ms_per_step']:.3f} ms/step; {rf_.get('kernel')} {rf_.get('avg_launch_ms', 0):.3f} ms = "
+            f"{rf_.get('achieved') or 0:.0f} GB/s = {rf_.get('frac') or 0:.3f} of {HBM_PEAK_GBPS:.0f}, traffic {rf_.get('traffic')} B"
+            + (f"; cpu {cb_['value']:.4g} k-mers/s on {cb_['cores']} threads" if cb_ else ""))
     if multi:
         dist.barrier()
         dist.destroy_process_group()

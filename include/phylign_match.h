@@ -161,9 +161,11 @@ int  pm_index_load_fd(int fd, uint64_t size_hint, int layout, pm_index_t** out);
 int  pm_index_load_mem(const void* buf, size_t len, int layout, pm_index_t** out);
 /* pm_index_load_fd that also keeps what it read: the decode-once cache of a compressed index (the reference's `mem-disk`
  * mode with keep_cobs_indexes: rule decompress_cobs, Snakefile:364-387, writes "<batch>.cobs_classic.tmp" and renames it).
- * Every byte of the stream goes to "<tee_path>.tmp", renamed to `tee_path` once the whole index is in HBM; a failed load
- * leaves nothing behind.  A failed write (disk full) does not fail the load: *cached (optional) says whether the
- * file exists now.  A later pm_index_load_file(tee_path) takes the parallel pread path. */
+ * Every byte of the stream goes to a file of this call's own in tee_path's directory -- an unnamed inode (O_TMPFILE) where
+ * the file system has them, so that even a killed process leaves nothing behind; "<tee_path>.XXXXXX.tmp" otherwise -- which
+ * becomes `tee_path` (link + rename) once the whole index is in HBM; a failed load leaves nothing behind; when another
+ * process published the same index meanwhile, this call's copy is dropped.  A failed write (disk full) does not fail the
+ * load: *cached (optional) says whether the file exists now.  A later pm_index_load_file(tee_path) takes the parallel pread path. */
 int  pm_index_load_fd_tee(int fd, uint64_t size_hint, int layout, const char* tee_path, int* cached, pm_index_t** out);
 /* header + document names only (no matrix): for the rank that formats text */
 int  pm_index_load_header_mem(const void* buf, size_t len, pm_index_t** out);

@@ -143,7 +143,7 @@ class FileSource:
 
     cache_dir: the decode-once cache (the reference's index_load_mode mem-disk + keep_cobs_indexes, config.yaml:91-104,
     rule decompress_cobs Snakefile:364-387): a batch that had to be decoded from .xz leaves
-    <cache_dir>/<batch>.cobs_classic behind (written while it streams into HBM, tmp + rename), and the next stage run
+    <cache_dir>/<batch>.cobs_classic behind (written while it streams into HBM: unnamed temporary + rename), and the next stage run
     reads that file with the parallel pread loader instead of decoding again."""
 
     def __init__(self, pm, cobs_dir, sizes, cache_dir=None, host_ram=None, host_mb=None):
@@ -625,7 +625,7 @@ def main(argv=None):
                          "(the sizes table's third column per decoder, Snakefile:64-69; the index itself is in HBM).  "
                          "0 = 80 %% of the RAM available now")
     ap.add_argument("--cache-dir", default=None,
-                    help="decode-once cache: a batch decoded from .xz is also written to <dir>/<batch>.cobs_classic (tmp + rename) "
+                    help="decode-once cache: a batch decoded from .xz is also written to <dir>/<batch>.cobs_classic (unnamed temporary + rename) "
                          "while it streams into HBM; later runs load that file (parallel pread, tens of GB/s) instead of "
                          "decoding again.  The reference's index_load_mode mem-disk with keep_cobs_indexes (config.yaml:91-104)")
     ap.add_argument("--index-load-mode", default="mem-stream", choices=["mem-stream", "mem-disk", "mmap-disk"],
